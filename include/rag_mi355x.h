@@ -1,0 +1,174 @@
+/*
+ * rag_mi355x.h -- C ABI of librag_mi355x.so, the MI355X (gfx950) engine behind
+ * RAG-system's search path.
+ *
+ * Every entry point replaces one call the reference makes into a third-party
+ * numeric library (faiss / rank_bm25 / scikit-learn).  The citation on each
+ * declaration is the reference call site (paths relative to the reference
+ * checkout) whose arithmetic the entry point performs on the GPU.
+ *
+ * Conventions
+ *   - All functions return 0 on success and a negative RAG_ERR_* code on
+ *     failure; rag_last_error() returns a thread-local message for the last
+ *     failure on the calling thread.
+ *   - The caller owns every host buffer; the library owns device memory.
+ *   - Pointers named *_dev are device pointers (HBM) on the device selected by
+ *     rag_init(); everything else is host memory.
+ *   - `stream` arguments are a hipStream_t passed as void* (NULL = the
+ *     library's own stream).  *_dev entry points are asynchronous on `stream`.
+ *   - One mutex per handle: add/search on one handle may be called from
+ *     different host threads (the reference UI does, UI_manager.py:753,883).
+ *   - There is NO CPU fallback: without a usable GPU rag_init() fails with
+ *     RAG_ERR_NO_DEVICE and every other call fails with RAG_ERR_NOT_INIT.
+ */
+#ifndef RAG_MI355X_H
+#define RAG_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAG_OK                 0
+#define RAG_ERR_INVALID_ARG   -1
+#define RAG_ERR_NO_DEVICE     -2
+#define RAG_ERR_NOT_INIT      -3
+#define RAG_ERR_HIP           -4
+#define RAG_ERR_OOM           -5
+#define RAG_ERR_UNSUPPORTED   -6
+
+#define RAG_METRIC_IP 0   /* faiss.METRIC_INNER_PRODUCT, IndexFlatIP  */
+#define RAG_METRIC_L2 1   /* faiss.METRIC_L2 (squared), IndexFlatL2   */
+
+#define RAG_DTYPE_F32  0  /* rows stored as float32 (faiss IndexFlat)      */
+#define RAG_DTYPE_BF16 1  /* rows stored as bfloat16 (RNE), fp32 accumulate */
+
+/* Largest k the fused scan+select kernels serve (faiss-gpu's own limit is
+ * 2048; the reference issues k in {top_k, 3*top_k, 9*top_k} = {10,30,90}). */
+#define RAG_MAX_K 256
+
+typedef struct rag_flat rag_flat_t;
+typedef struct rag_csc  rag_csc_t;
+
+/* ---- library ---------------------------------------------------------- */
+
+/* Select HIP device `device_id` for this process (one process per GPU) and
+ * create the library stream.  Idempotent for the same device. */
+int rag_init(int device_id);
+/* Thread-local text of the last error on this thread ("" if none). */
+const char* rag_last_error(void);
+/* Number of HIP devices visible (0 if none / no driver). */
+int rag_device_count(void);
+/* ABI version of this header (bumped on incompatible change). */
+int rag_abi_version(void);
+
+/* ---- dense flat index -------------------------------------------------- */
+
+/* faiss.IndexFlatIP(d) / IndexFlatL2(d): vector_storage.py:79,146,151. */
+int rag_flat_create(int d, int metric, int storage_dtype, rag_flat_t** out);
+/* Destroy the index and free its HBM. */
+void rag_flat_free(rag_flat_t* h);
+/* Pre-size the HBM arena for `n_capacity` rows (optional). */
+int rag_flat_reserve(rag_flat_t* h, int64_t n_capacity);
+/* index.add(x): vector_storage.py:105 (one row per call) and :152 (bulk).
+ * x is row-major n*d float32 on the host.  Rows are staged and flushed to HBM
+ * in large copies; ids are assigned sequentially from ntotal. */
+int rag_flat_add(rag_flat_t* h, int64_t n, const float* x);
+/* Same as rag_flat_add but the rows are already in HBM (n*d float32). */
+int rag_flat_add_dev(rag_flat_t* h, int64_t n, const float* x_dev, void* stream);
+/* Append n synthetic L2-normalised rows generated on the device by the
+ * counter-based generator of oracle/flat_ref.c:synth_row() (bit-identical),
+ * keyed by (seed, first_global_row + i).  Benchmark / test input only; no
+ * counterpart in the reference. */
+int rag_flat_add_synthetic(rag_flat_t* h, int64_t n, uint64_t seed, int64_t first_global_row);
+/* index.ntotal: vector_storage.py:193. */
+int64_t rag_flat_ntotal(const rag_flat_t* h);
+/* index.d */
+int rag_flat_dim(const rag_flat_t* h);
+/* index.reset() (rebuild_faiss_index creates a fresh index, :146,151). */
+int rag_flat_reset(rag_flat_t* h);
+/* D, I = index.search(q, k): vector_storage.py:196.
+ * q: nq*d float32; D: nq*k float32; I: nq*k int64, best first.
+ * IP: descending inner product; L2: ascending squared distance.
+ * Ties: lower id first.  k > ntotal: tail padded with I=-1 and
+ * D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= RAG_MAX_K. */
+int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I);
+/* Same, device-resident query and outputs, asynchronous on `stream`;
+ * returned ids are id_base + local row (id_base = first global row of this
+ * shard when the corpus is row-sharded over ranks). */
+int rag_flat_search_dev(rag_flat_t* h, int64_t nq, const float* q_dev, int k,
+                        float* D_dev, int64_t* I_dev, int64_t id_base, void* stream);
+/* Rows [first, first+n) back to the host as float32 (faiss.write_index,
+ * vector_storage.py:231, needs the raw vectors). */
+int rag_flat_copy_to_host(rag_flat_t* h, int64_t first, int64_t n, float* out);
+/* Merge `nlists` per-shard results (layout [nlists][nq][k], each list sorted
+ * best-first with pads last) into the global top-k.  Runs after the RCCL
+ * all-gather of per-rank candidates; metric decides the order. */
+int rag_topk_merge_dev(int metric, int nlists, int64_t nq, int k,
+                       const float* D_lists_dev, const int64_t* I_lists_dev,
+                       float* D_dev, int64_t* I_dev, void* stream);
+/* Kernel-time accounting for the dense scan kernel (the dominant kernel):
+ * when enabled, every search brackets the scan kernel with HIP events on the
+ * stream it is launched on. */
+int rag_flat_profiling(rag_flat_t* h, int enable);
+/* Synchronises, then returns the number of timed scan launches since the last
+ * call, the sum of their durations (ms) and the algorithmic bytes per launch
+ * (ntotal*d*sizeof(elem)). */
+int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double* bytes_per_launch);
+/* Tuning knobs for A/B runs in one process: "scan_blocks", "scan_nt",
+ * "scan_rows", "mfma_min_nq". Unknown name -> RAG_ERR_INVALID_ARG. */
+int rag_set_option(const char* name, int64_t value);
+
+/* ---- sparse scoring (BM25Okapi, TF-IDF cosine) ------------------------- */
+
+/* Term-major (CSC) postings in HBM: for term t, postings
+ * [indptr[t], indptr[t+1]) hold (row[p], val[p]) = (chunk/doc index, weight).
+ * BM25: val = term frequency of t in the chunk (BM25Okapi state built at
+ * vector_storage.py:170,305).  TF-IDF: val = the L2-normalised tf-idf weight
+ * (TfidfVectorizer.fit_transform, vector_storage.py:216-217). */
+int rag_csc_create(int64_t n_terms, int64_t n_rows, const int64_t* indptr,
+                   const int32_t* row, const double* val, rag_csc_t** out);
+void rag_csc_free(rag_csc_t* h);
+/* BM25Okapi parameters: per-term idf (epsilon floor already applied), per-row
+ * token count, avgdl, k1, b (rank_bm25 BM25Okapi.__init__/_calc_idf). */
+int rag_bm25_set(rag_csc_t* h, const double* idf, const int32_t* doc_len,
+                 double avgdl, double k1, double b);
+/* scores = bm25.get_scores(tokens): vector_storage.py:178, then the stable
+ * descending sort + [:top_k] of :180.  term_ids are the query tokens in query
+ * order (repeats allowed, out-of-vocabulary tokens dropped by the caller:
+ * they add 0).  scores_or_null (n_rows float64) receives the dense score
+ * vector if non-NULL; D/I (k entries, k may exceed n_rows -> padded with
+ * I=-1, D=-DBL_MAX) receive the top-k (score desc, index asc).  k may be 0. */
+int rag_bm25_scores(rag_csc_t* h, int n_qterms, const int32_t* term_ids,
+                    double* scores_or_null, int k, double* D, int64_t* I);
+/* cosine_similarity(q, M)[0]: search_engine.py:284-285,330-331.  M's rows
+ * are unit-norm (val above), q_weights is the L2-normalised query row;
+ * term_ids ascending as scipy stores them.  Same outputs as rag_bm25_scores. */
+int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights,
+                     double* scores_or_null, int k, double* D, int64_t* I);
+/* Rank (0-based position in the stable descending sort of the LAST score
+ * vector computed on this handle) of each of n_query rows: search_engine.py
+ * :332-336 sorts ALL documents; RRF needs 1/(60+rank) only for candidates. */
+int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks);
+
+/* ---- candidate-set kernels -------------------------------------------- */
+
+/* reciprocal_rank_fusion(*rankings, k=60): search_engine.py:352-359.
+ * rankings are concatenated in `ids` (already in ranking order, best first),
+ * lens[r] entries each; every entry adds 1/(k_const+rank) to its id's score
+ * in ranking order.  Output: distinct ids in first-appearance order with their
+ * fused float64 scores; *n_out = number of distinct ids (<= sum lens). */
+int rag_rrf(int n_rankings, const int64_t* ids, const int64_t* lens, double k_const,
+            int64_t* out_ids, double* out_scores, int64_t* n_out);
+/* mmr_selection: search_engine.py:396-468.  cand: C*d float32 candidate
+ * embeddings (un-normalised), q: d float32 query embedding; byte_len: UTF-8
+ * length of each candidate text; max_bytes < 0 = no byte budget.
+ * out_order receives the selected candidate indices in selection order. */
+int rag_mmr(int C, int d, const float* cand, const float* q, double lambda, int top_k,
+            const int64_t* byte_len, int64_t max_bytes, int32_t* out_order, int* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAG_MI355X_H */

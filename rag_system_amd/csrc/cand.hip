@@ -1,0 +1,301 @@
+// cand.hip -- candidate-set kernels: Reciprocal Rank Fusion and MMR re-ranking.
+//
+// Replaces SearchEngine.reciprocal_rank_fusion (search_engine.py:352-359) and the numeric
+// part of SearchEngine.mmr_selection (search_engine.py:419-465).  Candidate sets are tiny
+// (tens to a few thousand entries), so each call is ONE workgroup; the work is latency-bound
+// and reported in microseconds, not against a roofline.  Compiled with -ffp-contract=off so
+// float64 sums match Python's.
+#include "common.h"
+
+#include <cfloat>
+#include <climits>
+#include <vector>
+
+namespace {
+
+using namespace rag;
+
+constexpr int CAND_THREADS = 1024;
+constexpr int RRF_MAX_ENTRIES = 16384;
+constexpr int MMR_MAX_C = 2048;
+
+// ids: all rankings concatenated (entry e belongs to ranking r with rank e - start[r]).
+// first[e] = smallest e' <= e with the same id.  An id's score is accumulated by the thread
+// owning its first entry, over its entries in order (= the order Python adds them).
+__global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __restrict__ ids,
+                                                           const int* __restrict__ rank_of, int T, double k_const,
+                                                           long long* __restrict__ out_ids,
+                                                           double* __restrict__ out_scores, int* __restrict__ n_out,
+                                                           int* __restrict__ first) {
+    __shared__ int s_count[CAND_THREADS];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < T; e += CAND_THREADS) {
+        const long long id = ids[e];
+        int f = e;
+        for (int j = 0; j < e; ++j)
+            if (ids[j] == id) {
+                f = j;
+                break;
+            }
+        first[e] = f;
+    }
+    __syncthreads();
+    // contiguous span per thread -> ordered compaction of distinct ids
+    const int per = (T + CAND_THREADS - 1) / CAND_THREADS;
+    const int lo = tid * per, hi = min(T, lo + per);
+    int cnt = 0;
+    for (int e = lo; e < hi; ++e) cnt += first[e] == e;
+    s_count[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < CAND_THREADS; ++i) {
+            const int c = s_count[i];
+            s_count[i] = run;
+            run += c;
+        }
+        *n_out = run;
+    }
+    __syncthreads();
+    int o = s_count[tid];
+    for (int e = lo; e < hi; ++e) {
+        if (first[e] != e) continue;
+        const long long id = ids[e];
+        double s = 0.0;
+        for (int j = e; j < T; ++j)
+            if (ids[j] == id) s = s + 1.0 / (k_const + (double)rank_of[j]);
+        out_ids[o] = id;
+        out_scores[o] = s;
+        ++o;
+    }
+}
+
+// MMR.  cand: C x d (un-normalised fp32), q: d.  Work arrays in HBM: nrm (C x d normalised),
+// G (C x C cosine), simq (C).  One workgroup; selection order written to out_order.
+__global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restrict__ cand, const float* __restrict__ q,
+                                                           int C, int d, double lambda, int top_k,
+                                                           const long long* __restrict__ byte_len, long long max_bytes,
+                                                           float* __restrict__ nrm, float* __restrict__ G,
+                                                           float* __restrict__ simq, int* __restrict__ out_order,
+                                                           int* __restrict__ out_n) {
+    __shared__ float s_inv[MMR_MAX_C];     // 1/||cand_i|| (fp32, zero norm -> 1e-9 as :422)
+    __shared__ float s_maxsim[MMR_MAX_C];  // max cosine to the selected set
+    __shared__ unsigned char s_state[MMR_MAX_C];  // 0 = candidate, 1 = selected/removed
+    __shared__ double s_best[CAND_THREADS / 64];
+    __shared__ int s_besti[CAND_THREADS / 64];
+    __shared__ float s_qinv;
+    __shared__ int s_pick;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = CAND_THREADS / 64;
+
+    // row norms (one wave per row), query norm
+    for (int i = wid; i <= C; i += NW) {
+        const float* v = i < C ? cand + (size_t)i * d : q;
+        float ss = 0.f;
+        for (int c = lane; c < d; c += 64) ss = fmaf(v[c], v[c], ss);
+        for (int dist = 32; dist >= 1; dist >>= 1) ss += __shfl_xor(ss, dist);
+        float n = sqrtf(ss);
+        if (i < C) {
+            if (n == 0.f) n = 1e-9f;
+            if (lane == 0) s_inv[i] = n;
+        } else if (lane == 0) {
+            s_qinv = n == 0.f ? 1.f : n;
+        }
+    }
+    __syncthreads();
+    for (size_t e = tid; e < (size_t)C * d; e += CAND_THREADS) nrm[e] = cand[e] / s_inv[e / d];
+    __syncthreads();
+    // cosine to the query and the Gram matrix (one wave per dot product)
+    for (int i = wid; i < C; i += NW) {
+        const float* a = nrm + (size_t)i * d;
+        float s = 0.f, na = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            s = fmaf(a[c], q[c], s);
+            na = fmaf(a[c], a[c], na);
+        }
+        for (int dist = 32; dist >= 1; dist >>= 1) {
+            s += __shfl_xor(s, dist);
+            na += __shfl_xor(na, dist);
+        }
+        // sklearn's cosine_similarity re-normalises both sides
+        na = sqrtf(na);
+        if (na == 0.f) na = 1.f;
+        if (lane == 0) {
+            simq[i] = s / (na * s_qinv);
+            s_inv[i] = na;  // now holds the norm of the normalised row (~1)
+        }
+    }
+    __syncthreads();
+    for (long long pr = wid; pr < (long long)C * C; pr += NW) {
+        const int i = (int)(pr / C), j = (int)(pr % C);
+        if (j < i) continue;
+        const float* a = nrm + (size_t)i * d;
+        const float* b = nrm + (size_t)j * d;
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) s = fmaf(a[c], b[c], s);
+        for (int dist = 32; dist >= 1; dist >>= 1) s += __shfl_xor(s, dist);
+        if (lane == 0) {
+            const float v = s / (s_inv[i] * s_inv[j]);
+            G[(size_t)i * C + j] = v;
+            G[(size_t)j * C + i] = v;
+        }
+    }
+    for (int i = tid; i < C; i += CAND_THREADS) {
+        s_state[i] = 0;
+        s_maxsim[i] = -FLT_MAX;
+    }
+    __syncthreads();
+
+    int n_sel = 0;
+    long long total_bytes = 0;
+    int last = -1;
+    bool first_pick = true;
+    int remaining = C;
+    while (remaining > 0 && n_sel < top_k) {
+        // score every live candidate; block argmax, first index wins ties (np.argmax)
+        double best = -DBL_MAX;
+        int besti = INT_MAX;
+        for (int i = tid; i < C; i += CAND_THREADS) {
+            if (s_state[i]) continue;
+            if (last >= 0) s_maxsim[i] = fmaxf(s_maxsim[i], G[(size_t)i * C + last]);
+            const double sc = first_pick ? (double)simq[i]
+                                         : lambda * (double)simq[i] - (1.0 - lambda) * (double)s_maxsim[i];
+            if (sc > best || (sc == best && i < besti)) {
+                best = sc;
+                besti = i;
+            }
+        }
+        for (int dist = 32; dist >= 1; dist >>= 1) {
+            const double ob = __shfl_xor(best, dist);
+            const int oi = __shfl_xor(besti, dist);
+            if (ob > best || (ob == best && oi < besti)) {
+                best = ob;
+                besti = oi;
+            }
+        }
+        if (lane == 0) {
+            s_best[wid] = best;
+            s_besti[wid] = besti;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double b = s_best[0];
+            int bi = s_besti[0];
+            for (int w = 1; w < NW; ++w)
+                if (s_best[w] > b || (s_best[w] == b && s_besti[w] < bi)) {
+                    b = s_best[w];
+                    bi = s_besti[w];
+                }
+            s_pick = bi;
+        }
+        __syncthreads();
+        const int pick = s_pick;
+        if (pick >= C) break;  // only NaN scores left: nothing selectable (block-uniform)
+        last = -1;
+        // byte budget (search_engine.py:457-463): the first pick is never checked (:437)
+        bool take = true;
+        if (!first_pick && max_bytes >= 0 && total_bytes + byte_len[pick] > max_bytes) take = false;
+        if (take) {
+            total_bytes += byte_len[pick];
+            if (tid == 0) out_order[n_sel] = pick;
+            ++n_sel;
+            last = pick;
+        }
+        if (tid == 0) s_state[pick] = 1;
+        --remaining;
+        first_pick = false;
+        __syncthreads();
+    }
+    if (tid == 0) *out_n = n_sel;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        RAG_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+        return RAG_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rag_rrf(int n_rankings, const int64_t* ids, const int64_t* lens, double k_const, int64_t* out_ids,
+            double* out_scores, int64_t* n_out) {
+    RAG_REQUIRE_INIT();
+    if (n_rankings < 0 || (n_rankings > 0 && !lens) || !n_out) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    int64_t T = 0;
+    for (int r = 0; r < n_rankings; ++r) {
+        if (lens[r] < 0) return fail(RAG_ERR_INVALID_ARG, "negative ranking length");
+        T += lens[r];
+    }
+    *n_out = 0;
+    if (T == 0) return RAG_OK;
+    if (!ids || !out_ids || !out_scores) return fail(RAG_ERR_INVALID_ARG, "NULL buffer");
+    if (T > RRF_MAX_ENTRIES)
+        return fail(RAG_ERR_UNSUPPORTED, "%lld ranking entries exceed the candidate-set limit %d", (long long)T,
+                    RRF_MAX_ENTRIES);
+    std::vector<int> rank_of((size_t)T);
+    {
+        int64_t e = 0;
+        for (int r = 0; r < n_rankings; ++r)
+            for (int64_t j = 0; j < lens[r]; ++j) rank_of[(size_t)e++] = (int)j;
+    }
+    hipStream_t st = lib_stream();
+    DevBuf<long long> d_ids, d_out_ids;
+    DevBuf<int> d_rank, d_first, d_n;
+    DevBuf<double> d_scores;
+    int rc;
+    if ((rc = d_ids.alloc(T)) || (rc = d_out_ids.alloc(T)) || (rc = d_rank.alloc(T)) || (rc = d_first.alloc(T)) ||
+        (rc = d_n.alloc(1)) || (rc = d_scores.alloc(T)))
+        return rc;
+    RAG_HIP(hipMemcpyAsync(d_ids.p, ids, (size_t)T * sizeof(long long), hipMemcpyHostToDevice, st));
+    RAG_HIP(hipMemcpyAsync(d_rank.p, rank_of.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
+    rrf_kernel<<<1, CAND_THREADS, 0, st>>>(d_ids.p, d_rank.p, (int)T, k_const, d_out_ids.p, d_scores.p, d_n.p,
+                                          d_first.p);
+    RAG_HIP(hipGetLastError());
+    int n = 0;
+    RAG_HIP(hipMemcpyAsync(&n, d_n.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipStreamSynchronize(st));
+    RAG_HIP(hipMemcpy(out_ids, d_out_ids.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    RAG_HIP(hipMemcpy(out_scores, d_scores.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    *n_out = n;
+    return RAG_OK;
+}
+
+int rag_mmr(int C, int d, const float* cand, const float* q, double lambda, int top_k, const int64_t* byte_len,
+            int64_t max_bytes, int32_t* out_order, int* out_n) {
+    RAG_REQUIRE_INIT();
+    if (C < 0 || d <= 0 || !out_n || top_k < 0) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    *out_n = 0;
+    if (C == 0 || top_k == 0) return RAG_OK;
+    if (!cand || !q || !byte_len || !out_order) return fail(RAG_ERR_INVALID_ARG, "NULL buffer");
+    if (C > MMR_MAX_C)
+        return fail(RAG_ERR_UNSUPPORTED, "%d candidates exceed the candidate-set limit %d", C, MMR_MAX_C);
+    hipStream_t st = lib_stream();
+    DevBuf<float> d_cand, d_q, d_nrm, d_G, d_simq;
+    DevBuf<long long> d_bytes;
+    DevBuf<int> d_order, d_n;
+    int rc;
+    if ((rc = d_cand.alloc((size_t)C * d)) || (rc = d_q.alloc(d)) || (rc = d_nrm.alloc((size_t)C * d)) ||
+        (rc = d_G.alloc((size_t)C * C)) || (rc = d_simq.alloc(C)) || (rc = d_bytes.alloc(C)) ||
+        (rc = d_order.alloc(C)) || (rc = d_n.alloc(1)))
+        return rc;
+    RAG_HIP(hipMemcpyAsync(d_cand.p, cand, (size_t)C * d * sizeof(float), hipMemcpyHostToDevice, st));
+    RAG_HIP(hipMemcpyAsync(d_q.p, q, (size_t)d * sizeof(float), hipMemcpyHostToDevice, st));
+    RAG_HIP(hipMemcpyAsync(d_bytes.p, byte_len, (size_t)C * sizeof(long long), hipMemcpyHostToDevice, st));
+    mmr_kernel<<<1, CAND_THREADS, 0, st>>>(d_cand.p, d_q.p, C, d, lambda, top_k, d_bytes.p, (long long)max_bytes,
+                                          d_nrm.p, d_G.p, d_simq.p, d_order.p, d_n.p);
+    RAG_HIP(hipGetLastError());
+    int n = 0;
+    RAG_HIP(hipMemcpyAsync(&n, d_n.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipStreamSynchronize(st));
+    if (n > 0) RAG_HIP(hipMemcpy(out_order, d_order.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    *out_n = n;
+    return RAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// common.h -- shared host-side plumbing of librag_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstdio>
+#include <cstdarg>
+#include <mutex>
+#include <string>
+
+#include "../../include/rag_mi355x.h"
+
+namespace rag {
+
+void set_error(const char* fmt, ...);
+int  fail(int code, const char* fmt, ...);
+bool initialized();
+int  device_id();
+hipStream_t lib_stream();
+int  num_cus();
+
+// Process-wide tuning knobs (rag_set_option).
+struct Options {
+    int64_t scan_blocks = 0;   // 0 = auto (CUs * blocks_per_cu)
+    int64_t scan_nt = 1;       // non-temporal loads for the streamed matrix
+    int64_t scan_rows = 0;     // rows per wave tile (0 = auto)
+    int64_t mfma_min_nq = 5;   // nq >= this -> MFMA batch kernel
+};
+Options& options();
+
+}  // namespace rag
+
+#define RAG_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return rag::fail(_e == hipErrorOutOfMemory ? RAG_ERR_OOM : RAG_ERR_HIP,          \
+                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                             __LINE__);                                                      \
+    } while (0)
+
+#define RAG_REQUIRE_INIT()                                                             \
+    do {                                                                               \
+        if (!rag::initialized())                                                       \
+            return rag::fail(RAG_ERR_NOT_INIT, "rag_init() has not succeeded in this process"); \
+    } while (0)

@@ -1,0 +1,737 @@
+// flat.hip -- exact dense retrieval: IndexFlatIP / IndexFlatL2 scan fused with top-k.
+//
+// Replaces faiss' IndexFlat.search (vector_storage.py:196) and .add (:105,:152).
+//
+// HBM layout: one arena per index, row-major, row stride `ld` elements (d rounded up to a
+// multiple of 4 floats so every row starts 16-byte aligned; pad columns are zero).
+//
+// Small query batches (nq <= 4 per pass): flat_scan_kernel -- a bandwidth-bound fused GEMV.
+//   * every wave streams tiles of R consecutive rows with 16-byte coalesced loads
+//     (lane l reads float4 l, l+64, ... of the row: 1 KiB contiguous per wave instruction),
+//   * the query sits in LDS, partial dot products stay in registers,
+//   * R*NQ partial sums are reduced across the wave at once (wave_multi_reduce),
+//   * rows that beat the wave's current k-th key are inserted into a register-resident
+//     sorted list (WaveTopK); the score matrix is never written,
+//   * the four waves of a block merge through LDS and write ONE k-list per block,
+//   * flat_merge_kernel (one block per query) merges the per-block lists.
+#include "common.h"
+#include "topk.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+using namespace rag;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+constexpr int MERGE_THREADS = 1024;
+constexpr int MERGE_WAVES = MERGE_THREADS / 64;
+
+// ---------------------------------------------------------------- scan kernel
+
+template <int METRIC>
+__device__ __forceinline__ float dot4_acc(f32x4 x, f32x4 q, float acc) {
+    if (METRIC == RAG_METRIC_IP) {
+        acc = fmaf(x.x, q.x, acc);
+        acc = fmaf(x.y, q.y, acc);
+        acc = fmaf(x.z, q.z, acc);
+        acc = fmaf(x.w, q.w, acc);
+    } else {
+        float t;
+        t = x.x - q.x; acc = fmaf(t, t, acc);
+        t = x.y - q.y; acc = fmaf(t, t, acc);
+        t = x.z - q.z; acc = fmaf(t, t, acc);
+        t = x.w - q.w; acc = fmaf(t, t, acc);
+    }
+    return acc;
+}
+
+template <int R, int NQ, int KS, int METRIC, bool NT>
+__global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
+    const f32x4* __restrict__ X4, long long n, int d4, const f32x4* __restrict__ Q4, int k,
+    float* __restrict__ cand_key, int* __restrict__ cand_id) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    f32x4* q_lds = reinterpret_cast<f32x4*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    for (int i = tid; i < NQ * d4; i += SCAN_THREADS) q_lds[i] = Q4[i];
+    __syncthreads();
+
+    using TK = WaveTopK<float, int, KS>;
+    TK tk[NQ];
+    float thr_k[NQ];
+    int thr_i[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        tk[q].init();
+        thr_k[q] = Lowest<float>::v();
+        thr_i[q] = IdPad<int>::v();
+    }
+
+    constexpr int N = R * NQ;
+    constexpr int LOGN = Log2<N>::v;
+    constexpr int REP = 64 / N;
+    const long long W = (long long)gridDim.x * SCAN_WAVES;
+    const long long gw = (long long)blockIdx.x * SCAN_WAVES + wid;
+    const long long ntiles = (n + R - 1) / R;
+    const int nchunk = (d4 + 63) >> 6;
+
+    for (long long t = gw; t < ntiles; t += W) {
+        const long long row0 = t * R;
+        float acc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.0f;
+
+        for (int c = 0; c < nchunk; ++c) {
+            const int idx = c * 64 + lane;
+            if (idx < d4) {
+                f32x4 xv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    long long row = row0 + r;
+                    row = row < n ? row : n - 1;
+                    const f32x4* p = X4 + row * d4 + idx;
+                    xv[r] = NT ? __builtin_nontemporal_load(p) : *p;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 qv = q_lds[q * d4 + idx];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[q * R + r] = dot4_acc<METRIC>(xv[r], qv, acc[q * R + r]);
+                }
+            }
+        }
+
+        const float tot = wave_multi_reduce<N>(acc, lane);
+        const int item = (lane >> (6 - LOGN)) & (N - 1);
+        const bool rep = (lane & (REP - 1)) == 0;
+        const int r_of = item % R, q_of = item / R;
+        const long long row = row0 + r_of;
+        const float key = (METRIC == RAG_METRIC_IP) ? tot : -tot;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], key, (int)row,
+                                       rep && q_of == q && row < n, lane);
+    }
+
+    // ---- merge the block's four wave lists through LDS, wave 0 writes one list per query
+    const int qbytes = ((NQ * d4 * 16) + 15) & ~15;
+    float* mk = reinterpret_cast<float*>(smem_raw + qbytes);
+    int* mi = reinterpret_cast<int*>(mk + (SCAN_WAVES - 1) * NQ * KS * 64);
+    if (wid > 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int o = (((wid - 1) * NQ + q) * KS + s) * 64 + lane;
+                mk[o] = tk[q].key[s];
+                mi[o] = tk[q].id[s];
+            }
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            for (int w = 0; w < SCAN_WAVES - 1; ++w)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int o = ((w * NQ + q) * KS + s) * 64 + lane;
+                    wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], mk[o], mi[o], true, lane);
+                }
+            const long long base = ((long long)q * gridDim.x + blockIdx.x) * k;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s * 64 + lane;
+                if (p < k) {
+                    cand_key[base + p] = tk[q].key[s];
+                    cand_id[base + p] = tk[q].id[s];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- merge kernels
+
+// Internal candidates [nq][nlists][k] (key = larger-is-better, id = local row, pads INT_MAX).
+template <int KS, int METRIC>
+__global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
+    const float* __restrict__ cand_key, const int* __restrict__ cand_id, int nlists, int k,
+    float* __restrict__ D, long long* __restrict__ I, long long id_base) {
+    __shared__ float mk[(MERGE_WAVES - 1) * KS * 64];
+    __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
+    const long long q = blockIdx.x;
+    const long long C = (long long)nlists * k;
+    const float* ck = cand_key + q * C;
+    const int* ci = cand_id + q * C;
+    WaveTopK<float, int, KS> tk;
+    block_merge<float, int, KS, MERGE_WAVES>(
+        [&](long long c, float& key, int& id) {
+            key = ck[c];
+            id = ci[c];
+            return id != IdPad<int>::v();
+        },
+        C, k, tk, mk, mi);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int p = s * 64 + lane;
+            if (p < k) {
+                const bool pad = tk.id[s] == IdPad<int>::v();
+                const float key = tk.key[s];
+                D[q * k + p] = pad ? (METRIC == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX)
+                                   : (METRIC == RAG_METRIC_IP ? key : -key);
+                I[q * k + p] = pad ? -1LL : id_base + (long long)tk.id[s];
+            }
+        }
+    }
+}
+
+// External per-shard results [nlists][nq][k] (faiss-format D / int64 I, pads I = -1).
+template <int KS>
+__global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
+    int metric, const float* __restrict__ Dl, const long long* __restrict__ Il, int nlists, long long nq,
+    int k, float* __restrict__ D, long long* __restrict__ I) {
+    __shared__ float mk[(MERGE_WAVES - 1) * KS * 64];
+    __shared__ long long mi[(MERGE_WAVES - 1) * KS * 64];
+    const long long q = blockIdx.x;
+    const long long C = (long long)nlists * k;
+    const bool ip = metric == RAG_METRIC_IP;
+    WaveTopK<float, long long, KS> tk;
+    block_merge<float, long long, KS, MERGE_WAVES>(
+        [&](long long c, float& key, long long& id) {
+            const long long l = c / k, j = c - l * k;
+            const long long o = (l * nq + q) * k + j;
+            id = Il[o];
+            const float v = Dl[o];
+            key = ip ? v : -v;
+            return id >= 0;
+        },
+        C, k, tk, mk, mi);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int p = s * 64 + lane;
+            if (p < k) {
+                const bool pad = tk.id[s] == IdPad<long long>::v();
+                const float key = tk.key[s];
+                D[q * k + p] = pad ? (ip ? -FLT_MAX : FLT_MAX) : (ip ? key : -key);
+                I[q * k + p] = pad ? -1LL : tk.id[s];
+            }
+        }
+    }
+}
+
+__global__ void fill_pad_kernel(float* D, long long* I, long long total, float dpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        D[i] = dpad;
+        I[i] = -1;
+    }
+}
+
+// Queries (nq x d) -> zero-padded (nq x ld).
+__global__ void pad_queries_kernel(const float* __restrict__ q, float* __restrict__ qpad, long long nq, int d,
+                                   int ld) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq * ld) {
+        const long long r = i / ld;
+        const int c = (int)(i - r * ld);
+        qpad[i] = c < d ? q[r * d + c] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------- synthetic rows
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ int synth_int(unsigned long long row_key, int col) {
+    const unsigned long long h = splitmix64(row_key + (unsigned long long)col);
+    const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) +
+                  (int)((h >> 48) & 0xFFFF);
+    return s - 131070;
+}
+
+// One wave per row; bit-identical to oracle/flat_ref.c:synth_row (integer sum of squares is
+// exact, sqrt and the division are IEEE double, one rounding to float).
+__global__ __launch_bounds__(256) void synth_rows_kernel(float* __restrict__ X, int ld, int d, long long n,
+                                                         unsigned long long seed, long long first_global) {
+    const int lane = threadIdx.x & 63;
+    const long long W = (long long)gridDim.x * 4;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += W) {
+        const unsigned long long key =
+            splitmix64(seed ^ ((unsigned long long)(first_global + r) * 0xD1B54A32D192ED03ULL));
+        unsigned long long ss = 0;
+        for (int c = lane; c < d; c += 64) {
+            const long long v = synth_int(key, c);
+            ss += (unsigned long long)(v * v);
+        }
+        for (int dist = 32; dist >= 1; dist >>= 1) ss += __shfl_xor(ss, dist);
+        const double nrm = sqrt((double)ss);
+        float* row = X + r * ld;
+        for (int c = lane; c < ld; c += 64)
+            row[c] = c < d ? (float)((double)synth_int(key, c) / nrm) : 0.0f;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- handle
+
+struct rag_flat {
+    int d = 0, ld = 0, metric = 0, dtype = 0;
+    int64_t ntotal = 0;      // rows visible to search (device rows + staged rows)
+    int64_t ndev = 0;        // rows resident in HBM
+    int64_t cap = 0;         // arena capacity in rows
+    float* x = nullptr;      // HBM arena, cap * ld floats
+    std::vector<float> staged;  // host rows not yet flushed (d floats each)
+    // search workspace (HBM)
+    float* ws_q = nullptr;   int64_t ws_q_cap = 0;     // padded queries
+    float* ws_key = nullptr; int64_t ws_key_cap = 0;
+    int* ws_id = nullptr;    int64_t ws_id_cap = 0;
+    float* ws_hq = nullptr;  int64_t ws_hq_cap = 0;    // host-variant device copies
+    float* ws_D = nullptr; long long* ws_I = nullptr; int64_t ws_out_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+    std::mutex mu;
+};
+
+namespace {
+
+constexpr int64_t STAGE_FLUSH_FLOATS = 16 << 20;  // 64 MiB of staged rows
+
+int ensure_capacity(rag_flat* h, int64_t rows) {
+    if (rows <= h->cap) return RAG_OK;
+    int64_t want = std::max<int64_t>(rows, std::max<int64_t>(h->cap * 2, 1024));
+    float* nx = nullptr;
+    hipError_t e = hipMalloc(&nx, (size_t)want * h->ld * sizeof(float));
+    if (e != hipSuccess && want > rows) {
+        (void)hipGetLastError();
+        want = rows;
+        e = hipMalloc(&nx, (size_t)want * h->ld * sizeof(float));
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RAG_ERR_OOM, "hipMalloc of %lld rows x %d floats failed: %s", (long long)want, h->ld,
+                    hipGetErrorString(e));
+    }
+    hipStream_t st = lib_stream();
+    if (h->ld != h->d)  // pad columns must read as zero
+        RAG_HIP(hipMemsetAsync(nx, 0, (size_t)want * h->ld * sizeof(float), st));
+    if (h->ndev > 0)
+        RAG_HIP(hipMemcpyAsync(nx, h->x, (size_t)h->ndev * h->ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RAG_HIP(hipStreamSynchronize(st));
+    if (h->x) RAG_HIP(hipFree(h->x));
+    h->x = nx;
+    h->cap = want;
+    return RAG_OK;
+}
+
+// Copy n host rows (d floats each) to arena rows [ndev, ndev+n).
+int upload_rows(rag_flat* h, const float* src, int64_t n) {
+    if (n <= 0) return RAG_OK;
+    int rc = ensure_capacity(h, h->ndev + n);
+    if (rc) return rc;
+    float* dst = h->x + (size_t)h->ndev * h->ld;
+    if (h->ld == h->d)
+        RAG_HIP(hipMemcpy(dst, src, (size_t)n * h->d * sizeof(float), hipMemcpyHostToDevice));
+    else
+        RAG_HIP(hipMemcpy2D(dst, (size_t)h->ld * sizeof(float), src, (size_t)h->d * sizeof(float),
+                            (size_t)h->d * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+    h->ndev += n;
+    return RAG_OK;
+}
+
+int flush_staged(rag_flat* h) {
+    if (h->staged.empty()) return RAG_OK;
+    const int64_t n = (int64_t)h->staged.size() / h->d;
+    int rc = upload_rows(h, h->staged.data(), n);
+    if (rc) return rc;
+    h->staged.clear();
+    h->staged.shrink_to_fit();
+    return RAG_OK;
+}
+
+template <typename T>
+int grow(T*& p, int64_t& cap, int64_t need) {
+    if (need <= cap) return RAG_OK;
+    if (p) RAG_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    const int64_t want = std::max<int64_t>(need, 1024);
+    RAG_HIP(hipMalloc(&p, (size_t)want * sizeof(T)));
+    cap = want;
+    return RAG_OK;
+}
+
+struct ScanCfg {
+    int R, NQ, KS, metric;
+    bool nt;
+};
+
+typedef void (*scan_fn_t)(const f32x4*, long long, int, const f32x4*, int, float*, int*);
+
+template <int R, int NQ, int KS>
+scan_fn_t pick_scan2(int metric, bool nt) {
+    if (metric == RAG_METRIC_IP)
+        return nt ? flat_scan_kernel<R, NQ, KS, RAG_METRIC_IP, true> : flat_scan_kernel<R, NQ, KS, RAG_METRIC_IP, false>;
+    return nt ? flat_scan_kernel<R, NQ, KS, RAG_METRIC_L2, true> : flat_scan_kernel<R, NQ, KS, RAG_METRIC_L2, false>;
+}
+template <int R, int NQ>
+scan_fn_t pick_scan1(int KS, int metric, bool nt) {
+    switch (KS) {
+        case 1: return pick_scan2<R, NQ, 1>(metric, nt);
+        case 2: return pick_scan2<R, NQ, 2>(metric, nt);
+        default: return pick_scan2<R, NQ, 4>(metric, nt);
+    }
+}
+scan_fn_t pick_scan(const ScanCfg& c) {
+    if (c.NQ == 1) {
+        if (c.R == 2) return pick_scan1<2, 1>(c.KS, c.metric, c.nt);
+        if (c.R == 8) return pick_scan1<8, 1>(c.KS, c.metric, c.nt);
+        return pick_scan1<4, 1>(c.KS, c.metric, c.nt);
+    }
+    if (c.NQ == 2) return pick_scan1<4, 2>(c.KS, c.metric, c.nt);
+    return pick_scan1<4, 4>(c.KS, c.metric, c.nt);
+}
+
+typedef void (*merge_fn_t)(const float*, const int*, int, int, float*, long long*, long long);
+merge_fn_t pick_merge(int KS, int metric) {
+    if (metric == RAG_METRIC_IP) {
+        if (KS == 1) return flat_merge_kernel<1, RAG_METRIC_IP>;
+        if (KS == 2) return flat_merge_kernel<2, RAG_METRIC_IP>;
+        return flat_merge_kernel<4, RAG_METRIC_IP>;
+    }
+    if (KS == 1) return flat_merge_kernel<1, RAG_METRIC_L2>;
+    if (KS == 2) return flat_merge_kernel<2, RAG_METRIC_L2>;
+    return flat_merge_kernel<4, RAG_METRIC_L2>;
+}
+
+int ks_for(int k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
+
+// The whole device-side search: q_dev (nq x d) -> D_dev/I_dev (nq x k) on `st`.
+int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_dev, long long* I_dev,
+                  int64_t id_base, hipStream_t st) {
+    const int64_t n = h->ndev;
+    if (n == 0) {
+        const long long total = nq * k;
+        fill_pad_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            D_dev, I_dev, total, h->metric == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX);
+        RAG_HIP(hipGetLastError());
+        return RAG_OK;
+    }
+    if (n > (int64_t)INT_MAX - 8)
+        return fail(RAG_ERR_UNSUPPORTED, "more than 2^31-9 rows in one shard (%lld)", (long long)n);
+    const int ld = h->ld, d4 = ld / 4;
+    const Options& opt = options();
+    const int KS = ks_for(k);
+
+    int rc = grow(h->ws_q, h->ws_q_cap, nq * ld);
+    if (rc) return rc;
+    {
+        const long long total = nq * ld;
+        pad_queries_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(q_dev, h->ws_q, nq, h->d, ld);
+        RAG_HIP(hipGetLastError());
+    }
+
+    int64_t blocks = opt.scan_blocks > 0 ? opt.scan_blocks : (int64_t)num_cus() * 4;
+    int Rsel = (opt.scan_rows == 2 || opt.scan_rows == 8) ? (int)opt.scan_rows : 4;
+
+    for (int64_t q0 = 0; q0 < nq;) {
+        const int64_t left = nq - q0;
+        const int NQ = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+        const int R = NQ == 1 ? Rsel : 4;
+        const int64_t ntiles = (n + R - 1) / R;
+        int64_t nb = std::min<int64_t>(blocks, (ntiles + SCAN_WAVES - 1) / SCAN_WAVES);
+        nb = std::max<int64_t>(nb, 1);
+        rc = grow(h->ws_key, h->ws_key_cap, (int64_t)NQ * nb * k);
+        if (rc) return rc;
+        rc = grow(h->ws_id, h->ws_id_cap, (int64_t)NQ * nb * k);
+        if (rc) return rc;
+        const size_t qbytes = (size_t)(((int64_t)NQ * d4 * 16 + 15) & ~15LL);
+        const size_t smem = qbytes + (size_t)(SCAN_WAVES - 1) * NQ * KS * 64 * 8;
+        if (smem > 160 * 1024)
+            return fail(RAG_ERR_UNSUPPORTED, "d=%d too large for the LDS-resident query (%zu B)", h->d, smem);
+        ScanCfg cfg{R, NQ, KS, h->metric, opt.scan_nt != 0};
+        scan_fn_t fn = pick_scan(cfg);
+        if (smem > 48 * 1024)
+            RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->prof) {
+            if (!h->ev_free.empty()) {
+                e0 = h->ev_free.back().first;
+                e1 = h->ev_free.back().second;
+                h->ev_free.pop_back();
+            } else {
+                RAG_HIP(hipEventCreate(&e0));
+                RAG_HIP(hipEventCreate(&e1));
+            }
+            RAG_HIP(hipEventRecord(e0, st));
+        }
+        fn<<<(unsigned)nb, SCAN_THREADS, smem, st>>>(reinterpret_cast<const f32x4*>(h->x), (long long)n, d4,
+                                                    reinterpret_cast<const f32x4*>(h->ws_q + q0 * ld), k,
+                                                    h->ws_key, h->ws_id);
+        RAG_HIP(hipGetLastError());
+        if (h->prof) {
+            RAG_HIP(hipEventRecord(e1, st));
+            h->ev_used.emplace_back(e0, e1);
+        }
+        merge_fn_t mf = pick_merge(KS, h->metric);
+        mf<<<(unsigned)NQ, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, (int)nb, k, D_dev + q0 * k,
+                                                   I_dev + q0 * k, (long long)id_base);
+        RAG_HIP(hipGetLastError());
+        q0 += NQ;
+    }
+    return RAG_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C ABI
+
+extern "C" {
+
+int rag_flat_create(int d, int metric, int storage_dtype, rag_flat_t** out) {
+    RAG_REQUIRE_INIT();
+    if (!out) return fail(RAG_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (d <= 0 || d > 8192) return fail(RAG_ERR_INVALID_ARG, "d=%d out of range [1,8192]", d);
+    if (metric != RAG_METRIC_IP && metric != RAG_METRIC_L2)
+        return fail(RAG_ERR_INVALID_ARG, "metric %d is neither IP(0) nor L2(1)", metric);
+    if (storage_dtype != RAG_DTYPE_F32)
+        return fail(RAG_ERR_UNSUPPORTED, "storage dtype %d not built yet (fp32 only)", storage_dtype);
+    rag_flat* h = new rag_flat();
+    h->d = d;
+    h->ld = (d + 3) & ~3;
+    h->metric = metric;
+    h->dtype = storage_dtype;
+    *out = h;
+    return RAG_OK;
+}
+
+void rag_flat_free(rag_flat_t* h) {
+    if (!h) return;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (lib_stream()) (void)hipStreamSynchronize(lib_stream());
+        (void)hipFree(h->x);
+        (void)hipFree(h->ws_q);
+        (void)hipFree(h->ws_key);
+        (void)hipFree(h->ws_id);
+        (void)hipFree(h->ws_hq);
+        (void)hipFree(h->ws_D);
+        (void)hipFree(h->ws_I);
+        for (auto& p : h->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        for (auto& p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    }
+    delete h;
+}
+
+int rag_flat_reserve(rag_flat_t* h, int64_t n_capacity) {
+    RAG_REQUIRE_INIT();
+    if (!h || n_capacity < 0) return fail(RAG_ERR_INVALID_ARG, "bad handle or capacity");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return ensure_capacity(h, n_capacity);
+}
+
+int rag_flat_add(rag_flat_t* h, int64_t n, const float* x) {
+    RAG_REQUIRE_INIT();
+    if (!h || n < 0 || (n > 0 && !x)) return fail(RAG_ERR_INVALID_ARG, "bad handle, n or x");
+    if (n == 0) return RAG_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int64_t nf = n * h->d;
+    if (nf >= STAGE_FLUSH_FLOATS) {  // bulk add: straight to HBM
+        int rc = flush_staged(h);
+        if (rc) return rc;
+        rc = upload_rows(h, x, n);
+        if (rc) return rc;
+    } else {
+        h->staged.insert(h->staged.end(), x, x + nf);
+        if ((int64_t)h->staged.size() >= STAGE_FLUSH_FLOATS) {
+            int rc = flush_staged(h);
+            if (rc) return rc;
+        }
+    }
+    h->ntotal += n;
+    return RAG_OK;
+}
+
+int rag_flat_add_dev(rag_flat_t* h, int64_t n, const float* x_dev, void* stream) {
+    RAG_REQUIRE_INIT();
+    if (!h || n < 0 || (n > 0 && !x_dev)) return fail(RAG_ERR_INVALID_ARG, "bad handle, n or x_dev");
+    if (n == 0) return RAG_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = flush_staged(h);
+    if (rc) return rc;
+    rc = ensure_capacity(h, h->ndev + n);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : lib_stream();
+    float* dst = h->x + (size_t)h->ndev * h->ld;
+    if (h->ld == h->d)
+        RAG_HIP(hipMemcpyAsync(dst, x_dev, (size_t)n * h->d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else
+        RAG_HIP(hipMemcpy2DAsync(dst, (size_t)h->ld * sizeof(float), x_dev, (size_t)h->d * sizeof(float),
+                                 (size_t)h->d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, st));
+    RAG_HIP(hipStreamSynchronize(st));
+    h->ndev += n;
+    h->ntotal += n;
+    return RAG_OK;
+}
+
+int rag_flat_add_synthetic(rag_flat_t* h, int64_t n, uint64_t seed, int64_t first_global_row) {
+    RAG_REQUIRE_INIT();
+    if (!h || n < 0) return fail(RAG_ERR_INVALID_ARG, "bad handle or n");
+    if (n == 0) return RAG_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = flush_staged(h);
+    if (rc) return rc;
+    rc = ensure_capacity(h, h->ndev + n);
+    if (rc) return rc;
+    hipStream_t st = lib_stream();
+    const int64_t nb = std::min<int64_t>((n + 3) / 4, (int64_t)num_cus() * 8);
+    synth_rows_kernel<<<(unsigned)nb, 256, 0, st>>>(h->x + (size_t)h->ndev * h->ld, h->ld, h->d, (long long)n,
+                                                   (unsigned long long)seed, (long long)first_global_row);
+    RAG_HIP(hipGetLastError());
+    RAG_HIP(hipStreamSynchronize(st));
+    h->ndev += n;
+    h->ntotal += n;
+    return RAG_OK;
+}
+
+int64_t rag_flat_ntotal(const rag_flat_t* h) { return h ? h->ntotal : -1; }
+int rag_flat_dim(const rag_flat_t* h) { return h ? h->d : -1; }
+
+int rag_flat_reset(rag_flat_t* h) {
+    RAG_REQUIRE_INIT();
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "bad handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->staged.clear();
+    h->ntotal = 0;
+    h->ndev = 0;
+    return RAG_OK;
+}
+
+int rag_flat_search_dev(rag_flat_t* h, int64_t nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev,
+                        int64_t id_base, void* stream) {
+    RAG_REQUIRE_INIT();
+    if (!h || nq < 0 || (nq > 0 && (!q_dev || !D_dev || !I_dev)))
+        return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
+    if (k < 1 || k > RAG_MAX_K) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K);
+    if (nq == 0) return RAG_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = flush_staged(h);
+    if (rc) return rc;
+    return search_device(h, nq, q_dev, k, D_dev, reinterpret_cast<long long*>(I_dev), id_base,
+                         stream ? (hipStream_t)stream : lib_stream());
+}
+
+int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I) {
+    RAG_REQUIRE_INIT();
+    if (!h || nq < 0 || (nq > 0 && (!q || !D || !I)))
+        return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
+    if (k < 1 || k > RAG_MAX_K) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K);
+    if (nq == 0) return RAG_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = flush_staged(h);
+    if (rc) return rc;
+    hipStream_t st = lib_stream();
+    rc = grow(h->ws_hq, h->ws_hq_cap, nq * h->d);
+    if (rc) return rc;
+    if (nq * k > h->ws_out_cap) {
+        if (h->ws_D) RAG_HIP(hipFree(h->ws_D));
+        if (h->ws_I) RAG_HIP(hipFree(h->ws_I));
+        h->ws_D = nullptr; h->ws_I = nullptr; h->ws_out_cap = 0;
+        const int64_t want = std::max<int64_t>(nq * k, 1024);
+        RAG_HIP(hipMalloc(&h->ws_D, (size_t)want * sizeof(float)));
+        RAG_HIP(hipMalloc(&h->ws_I, (size_t)want * sizeof(long long)));
+        h->ws_out_cap = want;
+    }
+    RAG_HIP(hipMemcpyAsync(h->ws_hq, q, (size_t)nq * h->d * sizeof(float), hipMemcpyHostToDevice, st));
+    rc = search_device(h, nq, h->ws_hq, k, h->ws_D, h->ws_I, 0, st);
+    if (rc) return rc;
+    RAG_HIP(hipMemcpyAsync(D, h->ws_D, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(I, h->ws_I, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipStreamSynchronize(st));
+    return RAG_OK;
+}
+
+int rag_flat_copy_to_host(rag_flat_t* h, int64_t first, int64_t n, float* out) {
+    RAG_REQUIRE_INIT();
+    if (!h || first < 0 || n < 0 || (n > 0 && !out)) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (first + n > h->ntotal)
+        return fail(RAG_ERR_INVALID_ARG, "rows [%lld,%lld) exceed ntotal=%lld", (long long)first,
+                    (long long)(first + n), (long long)h->ntotal);
+    if (n == 0) return RAG_OK;
+    int rc = flush_staged(h);
+    if (rc) return rc;
+    RAG_HIP(hipStreamSynchronize(lib_stream()));
+    const float* src = h->x + (size_t)first * h->ld;
+    if (h->ld == h->d)
+        RAG_HIP(hipMemcpy(out, src, (size_t)n * h->d * sizeof(float), hipMemcpyDeviceToHost));
+    else
+        RAG_HIP(hipMemcpy2D(out, (size_t)h->d * sizeof(float), src, (size_t)h->ld * sizeof(float),
+                            (size_t)h->d * sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
+    return RAG_OK;
+}
+
+int rag_topk_merge_dev(int metric, int nlists, int64_t nq, int k, const float* Dl, const int64_t* Il,
+                       float* D, int64_t* I, void* stream) {
+    RAG_REQUIRE_INIT();
+    if (nlists < 1 || nq < 0 || k < 1 || k > RAG_MAX_K || !Dl || !Il || !D || !I)
+        return fail(RAG_ERR_INVALID_ARG, "bad argument to rag_topk_merge_dev");
+    if (metric != RAG_METRIC_IP && metric != RAG_METRIC_L2) return fail(RAG_ERR_INVALID_ARG, "bad metric");
+    if (nq == 0) return RAG_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : lib_stream();
+    const int KS = ks_for(k);
+    const long long* Ill = reinterpret_cast<const long long*>(Il);
+    long long* Io = reinterpret_cast<long long*>(I);
+    if (KS == 1) ext_merge_kernel<1><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io);
+    else if (KS == 2) ext_merge_kernel<2><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io);
+    else ext_merge_kernel<4><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io);
+    RAG_HIP(hipGetLastError());
+    return RAG_OK;
+}
+
+int rag_flat_profiling(rag_flat_t* h, int enable) {
+    RAG_REQUIRE_INIT();
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "bad handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->prof = enable != 0;
+    return RAG_OK;
+}
+
+int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double* bytes_per_launch) {
+    RAG_REQUIRE_INIT();
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "bad handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    int64_t cnt = 0;
+    double sum = 0.0;
+    for (auto& p : h->ev_used) {
+        RAG_HIP(hipEventSynchronize(p.second));
+        float ms = 0.f;
+        RAG_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        sum += ms;
+        ++cnt;
+        h->ev_free.push_back(p);
+    }
+    h->ev_used.clear();
+    if (n_launches) *n_launches = cnt;
+    if (total_ms) *total_ms = sum;
+    if (bytes_per_launch) *bytes_per_launch = (double)h->ndev * h->d * sizeof(float);
+    return RAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// lib.hip -- process-level state of librag_mi355x.so: device selection, error text, options.
+#include "common.h"
+
+#include <cstring>
+
+namespace rag {
+
+static thread_local std::string g_err;
+static std::mutex g_init_mu;
+static bool g_init = false;
+static int g_dev = -1;
+static int g_cus = 256;
+static hipStream_t g_stream = nullptr;
+static Options g_opt;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+bool initialized() { return g_init; }
+int device_id() { return g_dev; }
+hipStream_t lib_stream() { return g_stream; }
+int num_cus() { return g_cus; }
+Options& options() { return g_opt; }
+
+}  // namespace rag
+
+extern "C" {
+
+int rag_abi_version(void) { return 1; }
+
+const char* rag_last_error(void) { return rag::g_err.c_str(); }
+
+int rag_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rag_init(int device_id) {
+    std::lock_guard<std::mutex> lk(rag::g_init_mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return rag::fail(RAG_ERR_NO_DEVICE,
+                         "no HIP device visible (%s); this engine has no CPU fallback",
+                         e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return rag::fail(RAG_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, n);
+    if (rag::g_init) {
+        if (rag::g_dev == device_id) return RAG_OK;
+        return rag::fail(RAG_ERR_INVALID_ARG,
+                         "already initialised on device %d (one process per GPU)", rag::g_dev);
+    }
+    RAG_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    RAG_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return rag::fail(RAG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                         device_id, prop.gcnArchName);
+    rag::g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    RAG_HIP(hipStreamCreateWithFlags(&rag::g_stream, hipStreamNonBlocking));
+    rag::g_dev = device_id;
+    rag::g_init = true;
+    return RAG_OK;
+}
+
+int rag_set_option(const char* name, int64_t value) {
+    if (!name) return rag::fail(RAG_ERR_INVALID_ARG, "option name is NULL");
+    rag::Options& o = rag::options();
+    if (!std::strcmp(name, "scan_blocks")) o.scan_blocks = value;
+    else if (!std::strcmp(name, "scan_nt")) o.scan_nt = value;
+    else if (!std::strcmp(name, "scan_rows")) o.scan_rows = value;
+    else if (!std::strcmp(name, "mfma_min_nq")) o.mfma_min_nq = value;
+    else return rag::fail(RAG_ERR_INVALID_ARG, "unknown option '%s'", name);
+    return RAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,386 @@
+// sparse.hip -- BM25Okapi and TF-IDF cosine scoring over term-major postings (float64).
+//
+// Replaces rank_bm25's BM25Okapi.get_scores (vector_storage.py:178) + the stable descending
+// sort of :180, and sklearn's cosine_similarity(q, M)[0] (search_engine.py:285,331).
+//
+// Compiled with -ffp-contract=off: every score is the same sequence of IEEE float64
+// operations numpy / scipy perform on the host (no fused multiply-add), and query terms are
+// applied one kernel launch after another on one stream, so each row's additions happen in
+// query-term order exactly as `score += ...` does in the reference loop.  Within one term a
+// row appears at most once, so the read-modify-write needs no atomics and is deterministic.
+//
+// HBM layout: term-major postings (CSC of the rows x terms matrix): indptr[n_terms+1] int64,
+// row[nnz] int32, val[nnz] float64; dense float64 score vector of n_rows.
+#include "common.h"
+#include "topk.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+using namespace rag;
+
+constexpr int TK_THREADS = 256;
+constexpr int TK_WAVES = TK_THREADS / 64;
+constexpr int MERGE_THREADS = 1024;
+constexpr int MERGE_WAVES = MERGE_THREADS / 64;
+
+// score[row] += idf * ( tf*(k1+1) / ( tf + k1*((1-b) + (b*len)/avgdl) ) )   -- rank_bm25 order
+__global__ void bm25_term_kernel(const int* __restrict__ row, const double* __restrict__ val, long long begin,
+                                 long long end, double idf, const int* __restrict__ doc_len, double avgdl,
+                                 double k1, double b, double k1p1, double one_minus_b,
+                                 double* __restrict__ score) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; p < end; p += stride) {
+        const int r = row[p];
+        const double tf = val[p];
+        const double num = tf * k1p1;
+        const double t1 = b * (double)doc_len[r];
+        const double t2 = t1 / avgdl;
+        const double t3 = one_minus_b + t2;
+        const double t4 = k1 * t3;
+        const double den = tf + t4;
+        const double frac = num / den;
+        const double c = idf * frac;
+        score[r] = score[r] + c;
+    }
+}
+
+// score[row] += w * val   -- scipy csr_matmat order (one query term at a time)
+__global__ void tfidf_term_kernel(const int* __restrict__ row, const double* __restrict__ val, long long begin,
+                                  long long end, double w, double* __restrict__ score) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; p < end; p += stride) {
+        const int r = row[p];
+        const double prod = w * val[p];
+        score[r] = score[r] + prod;
+    }
+}
+
+// Per-block top-k of a dense float64 score vector (key desc, index asc).
+template <int KS>
+__global__ __launch_bounds__(TK_THREADS) void dense_topk_kernel(const double* __restrict__ score, long long n,
+                                                                int k, double* __restrict__ cand_key,
+                                                                int* __restrict__ cand_id) {
+    __shared__ double mk[(TK_WAVES - 1) * KS * 64];
+    __shared__ int mi[(TK_WAVES - 1) * KS * 64];
+    // contiguous span per block so that in-wave ids ascend
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = lo + per < n ? lo + per : n;
+    const long long C = hi > lo ? hi - lo : 0;
+    WaveTopK<double, int, KS> tk;
+    block_merge<double, int, KS, TK_WAVES>(
+        [&](long long c, double& key, int& id) {
+            key = score[lo + c];
+            id = (int)(lo + c);
+            return true;
+        },
+        C, k, tk, mk, mi);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const long long base = (long long)blockIdx.x * k;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int p = s * 64 + lane;
+            if (p < k) {
+                cand_key[base + p] = tk.key[s];
+                cand_id[base + p] = tk.id[s];
+            }
+        }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const double* __restrict__ cand_key,
+                                                                         const int* __restrict__ cand_id,
+                                                                         int nlists, int k, double* __restrict__ D,
+                                                                         long long* __restrict__ I) {
+    __shared__ double mk[(MERGE_WAVES - 1) * KS * 64];
+    __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
+    const long long C = (long long)nlists * k;
+    WaveTopK<double, int, KS> tk;
+    block_merge<double, int, KS, MERGE_WAVES>(
+        [&](long long c, double& key, int& id) {
+            key = cand_key[c];
+            id = cand_id[c];
+            return id != IdPad<int>::v();
+        },
+        C, k, tk, mk, mi);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int p = s * 64 + lane;
+            if (p < k) {
+                const bool pad = tk.id[s] == IdPad<int>::v();
+                D[p] = pad ? -DBL_MAX : tk.key[s];
+                I[p] = pad ? -1LL : (long long)tk.id[s];
+            }
+        }
+    }
+}
+
+// rank[i] = #{ j : s_j > s_q(i)  or  (s_j == s_q(i) and j < q(i)) }  for nq queried rows.
+constexpr int RANK_MAXQ = 1024;
+__global__ __launch_bounds__(256) void rank_kernel(const double* __restrict__ score, long long n, int nq,
+                                                   const long long* __restrict__ qrow,
+                                                   unsigned long long* __restrict__ rank) {
+    __shared__ double qs[RANK_MAXQ];
+    __shared__ long long qr[RANK_MAXQ];
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+        qr[i] = qrow[i];
+        qs[i] = score[qrow[i]];
+    }
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    // every thread of a wave runs the same trip count so the shuffles below are uniform
+    const long long j0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long trips = (n + stride - 1) / stride;
+    for (int i = 0; i < nq; ++i) {
+        const double s = qs[i];
+        const long long r = qr[i];
+        unsigned int cnt = 0;
+        long long j = j0;
+        for (long long t = 0; t < trips; ++t, j += stride)
+            if (j < n) {
+                const double v = score[j];
+                cnt += (v > s || (v == s && j < r)) ? 1u : 0u;
+            }
+        for (int dist = 32; dist >= 1; dist >>= 1) cnt += __shfl_xor(cnt, dist);
+        if (lane == 0 && cnt) atomicAdd(&rank[i], (unsigned long long)cnt);
+    }
+}
+
+}  // namespace
+
+struct rag_csc {
+    int64_t n_terms = 0, n_rows = 0, nnz = 0;
+    std::vector<int64_t> indptr;  // host copy: launch bounds per term
+    int* row = nullptr;
+    double* val = nullptr;
+    double* score = nullptr;
+    bool have_scores = false;
+    // bm25
+    bool bm25 = false;
+    std::vector<double> idf;
+    int* doc_len = nullptr;
+    double avgdl = 0, k1 = 0, b = 0;
+    // top-k workspace
+    double* cand_key = nullptr; int* cand_id = nullptr; int64_t cand_cap = 0;
+    double* out_D = nullptr; long long* out_I = nullptr; int64_t out_cap = 0;
+    long long* rk_rows = nullptr; unsigned long long* rk_out = nullptr;
+    std::mutex mu;
+};
+
+namespace {
+
+int ks_for(int k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
+
+int term_grid(long long len) {
+    long long nb = (len + 255) / 256;
+    const long long cap = (long long)num_cus() * 8;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// Dense top-k of h->score into host D/I (k entries; pads when k > n_rows).
+int topk_scores(rag_csc* h, int k, double* D, int64_t* I, hipStream_t st) {
+    if (k <= 0) return RAG_OK;
+    if (k > RAG_MAX_K) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [0,%d]", k, RAG_MAX_K);
+    const int KS = ks_for(k);
+    long long nb = (h->n_rows + 4095) / 4096;  // >= 4096 rows per block
+    nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
+    if (nb * k > h->cand_cap) {
+        if (h->cand_key) RAG_HIP(hipFree(h->cand_key));
+        if (h->cand_id) RAG_HIP(hipFree(h->cand_id));
+        h->cand_key = nullptr; h->cand_id = nullptr; h->cand_cap = 0;
+        const int64_t want = std::max<int64_t>(nb * k, 4096);
+        RAG_HIP(hipMalloc(&h->cand_key, (size_t)want * sizeof(double)));
+        RAG_HIP(hipMalloc(&h->cand_id, (size_t)want * sizeof(int)));
+        h->cand_cap = want;
+    }
+    if (k > h->out_cap) {
+        if (h->out_D) RAG_HIP(hipFree(h->out_D));
+        if (h->out_I) RAG_HIP(hipFree(h->out_I));
+        h->out_D = nullptr; h->out_I = nullptr; h->out_cap = 0;
+        RAG_HIP(hipMalloc(&h->out_D, (size_t)RAG_MAX_K * sizeof(double)));
+        RAG_HIP(hipMalloc(&h->out_I, (size_t)RAG_MAX_K * sizeof(long long)));
+        h->out_cap = RAG_MAX_K;
+    }
+#define LAUNCH_TOPK(KSV)                                                                                   \
+    do {                                                                                                   \
+        dense_topk_kernel<KSV><<<(unsigned)nb, TK_THREADS, 0, st>>>(h->score, (long long)h->n_rows, k,     \
+                                                                    h->cand_key, h->cand_id);             \
+        dense_topk_merge_kernel<KSV><<<1, MERGE_THREADS, 0, st>>>(h->cand_key, h->cand_id, (int)nb, k,     \
+                                                                  h->out_D, h->out_I);                     \
+    } while (0)
+    if (KS == 1) LAUNCH_TOPK(1);
+    else if (KS == 2) LAUNCH_TOPK(2);
+    else LAUNCH_TOPK(4);
+#undef LAUNCH_TOPK
+    RAG_HIP(hipGetLastError());
+    RAG_HIP(hipMemcpyAsync(D, h->out_D, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(I, h->out_I, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, st));
+    return RAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rag_csc_create(int64_t n_terms, int64_t n_rows, const int64_t* indptr, const int32_t* row, const double* val,
+                   rag_csc_t** out) {
+    RAG_REQUIRE_INIT();
+    if (!out) return fail(RAG_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_terms < 0 || n_rows < 0 || !indptr) return fail(RAG_ERR_INVALID_ARG, "bad sizes or indptr");
+    if (n_rows > (int64_t)INT_MAX - 8) return fail(RAG_ERR_UNSUPPORTED, "more than 2^31-9 rows");
+    if (indptr[0] != 0) return fail(RAG_ERR_INVALID_ARG, "indptr[0] must be 0");
+    for (int64_t t = 0; t < n_terms; ++t)
+        if (indptr[t + 1] < indptr[t]) return fail(RAG_ERR_INVALID_ARG, "indptr not monotone at term %lld", (long long)t);
+    const int64_t nnz = indptr[n_terms];
+    if (nnz > 0 && (!row || !val)) return fail(RAG_ERR_INVALID_ARG, "row/val NULL with nnz > 0");
+    for (int64_t p = 0; p < nnz; ++p)
+        if (row[p] < 0 || row[p] >= n_rows)
+            return fail(RAG_ERR_INVALID_ARG, "posting %lld has row %d outside [0,%lld)", (long long)p, row[p],
+                        (long long)n_rows);
+    rag_csc* h = new rag_csc();
+    h->n_terms = n_terms;
+    h->n_rows = n_rows;
+    h->nnz = nnz;
+    h->indptr.assign(indptr, indptr + n_terms + 1);
+    hipError_t e = hipSuccess;
+    if (nnz > 0) {
+        e = hipMalloc(&h->row, (size_t)nnz * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc(&h->val, (size_t)nnz * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(h->row, row, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc(&h->score, (size_t)std::max<int64_t>(n_rows, 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->rk_rows, RANK_MAXQ * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(&h->rk_out, RANK_MAXQ * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        rag_csc_free(h);
+        return fail(e == hipErrorOutOfMemory ? RAG_ERR_OOM : RAG_ERR_HIP, "rag_csc_create: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return RAG_OK;
+}
+
+void rag_csc_free(rag_csc_t* h) {
+    if (!h) return;
+    if (lib_stream()) (void)hipStreamSynchronize(lib_stream());
+    (void)hipFree(h->row);
+    (void)hipFree(h->val);
+    (void)hipFree(h->score);
+    (void)hipFree(h->doc_len);
+    (void)hipFree(h->cand_key);
+    (void)hipFree(h->cand_id);
+    (void)hipFree(h->out_D);
+    (void)hipFree(h->out_I);
+    (void)hipFree(h->rk_rows);
+    (void)hipFree(h->rk_out);
+    delete h;
+}
+
+int rag_bm25_set(rag_csc_t* h, const double* idf, const int32_t* doc_len, double avgdl, double k1, double b) {
+    RAG_REQUIRE_INIT();
+    if (!h || (h->n_terms > 0 && !idf) || (h->n_rows > 0 && !doc_len)) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->idf.assign(idf, idf + h->n_terms);
+    if (!h->doc_len) RAG_HIP(hipMalloc(&h->doc_len, (size_t)std::max<int64_t>(h->n_rows, 1) * sizeof(int)));
+    if (h->n_rows > 0)
+        RAG_HIP(hipMemcpy(h->doc_len, doc_len, (size_t)h->n_rows * sizeof(int), hipMemcpyHostToDevice));
+    h->avgdl = avgdl;
+    h->k1 = k1;
+    h->b = b;
+    h->bm25 = true;
+    return RAG_OK;
+}
+
+int rag_bm25_scores(rag_csc_t* h, int n_qterms, const int32_t* term_ids, double* scores_or_null, int k, double* D,
+                    int64_t* I) {
+    RAG_REQUIRE_INIT();
+    if (!h || n_qterms < 0 || (n_qterms > 0 && !term_ids) || k < 0 || (k > 0 && (!D || !I)))
+        return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->bm25) return fail(RAG_ERR_INVALID_ARG, "rag_bm25_set has not been called on this handle");
+    for (int i = 0; i < n_qterms; ++i)
+        if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
+            return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
+    hipStream_t st = lib_stream();
+    if (h->n_rows > 0) RAG_HIP(hipMemsetAsync(h->score, 0, (size_t)h->n_rows * sizeof(double), st));
+    // Python evaluates (self.k1 + 1) and (1 - self.b) once per term as float64 scalars.
+    const double k1p1 = h->k1 + 1.0, omb = 1.0 - h->b;
+    for (int i = 0; i < n_qterms; ++i) {
+        const int t = term_ids[i];
+        const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
+        if (b1 <= b0) continue;
+        bm25_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, h->idf[t], h->doc_len, h->avgdl,
+                                                            h->k1, h->b, k1p1, omb, h->score);
+    }
+    RAG_HIP(hipGetLastError());
+    h->have_scores = true;
+    if (scores_or_null && h->n_rows > 0)
+        RAG_HIP(hipMemcpyAsync(scores_or_null, h->score, (size_t)h->n_rows * sizeof(double), hipMemcpyDeviceToHost, st));
+    int rc = topk_scores(h, k, D, I, st);
+    if (rc) return rc;
+    RAG_HIP(hipStreamSynchronize(st));
+    return RAG_OK;
+}
+
+int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights,
+                     double* scores_or_null, int k, double* D, int64_t* I) {
+    RAG_REQUIRE_INIT();
+    if (!h || nnz_q < 0 || (nnz_q > 0 && (!term_ids || !q_weights)) || k < 0 || (k > 0 && (!D || !I)))
+        return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int i = 0; i < nnz_q; ++i)
+        if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
+            return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
+    hipStream_t st = lib_stream();
+    if (h->n_rows > 0) RAG_HIP(hipMemsetAsync(h->score, 0, (size_t)h->n_rows * sizeof(double), st));
+    for (int i = 0; i < nnz_q; ++i) {
+        const int t = term_ids[i];
+        const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
+        if (b1 <= b0) continue;
+        tfidf_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, q_weights[i], h->score);
+    }
+    RAG_HIP(hipGetLastError());
+    h->have_scores = true;
+    if (scores_or_null && h->n_rows > 0)
+        RAG_HIP(hipMemcpyAsync(scores_or_null, h->score, (size_t)h->n_rows * sizeof(double), hipMemcpyDeviceToHost, st));
+    int rc = topk_scores(h, k, D, I, st);
+    if (rc) return rc;
+    RAG_HIP(hipStreamSynchronize(st));
+    return RAG_OK;
+}
+
+int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks) {
+    RAG_REQUIRE_INIT();
+    if (!h || n_query < 0 || (n_query > 0 && (!rows || !ranks))) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->have_scores) return fail(RAG_ERR_INVALID_ARG, "no score vector has been computed on this handle");
+    for (int i = 0; i < n_query; ++i)
+        if (rows[i] < 0 || rows[i] >= h->n_rows)
+            return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)rows[i], (long long)h->n_rows);
+    hipStream_t st = lib_stream();
+    for (int q0 = 0; q0 < n_query; q0 += RANK_MAXQ) {
+        const int nq = std::min(RANK_MAXQ, n_query - q0);
+        RAG_HIP(hipMemcpyAsync(h->rk_rows, rows + q0, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
+        RAG_HIP(hipMemsetAsync(h->rk_out, 0, (size_t)nq * sizeof(unsigned long long), st));
+        long long nb = (h->n_rows + 1023) / 1024;
+        nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
+        rank_kernel<<<(unsigned)nb, 256, 0, st>>>(h->score, (long long)h->n_rows, nq, h->rk_rows, h->rk_out);
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipMemcpyAsync(ranks + q0, h->rk_out, (size_t)nq * sizeof(long long), hipMemcpyDeviceToHost, st));
+        RAG_HIP(hipStreamSynchronize(st));
+    }
+    return RAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// topk.h -- wave64 register-resident sorted top-k list and helpers (gfx950).
+//
+// One wave keeps the KS*64 best (key, id) pairs seen so far, sorted best-first and spread
+// over the lanes: list position p lives in lane p%64 of register slot p/64.  "Best" is
+// key descending, id ascending -- the order Python's stable sorted(..., reverse=True)
+// produces (vector_storage.py:180) and the tie rule this engine uses for faiss results.
+// Insertions are rare once the list is warm (a streamed row has to beat the current k-th
+// key), so they are done cooperatively by the whole wave: one ballot to find the position,
+// one lane shift per slot.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <climits>
+
+namespace rag {
+
+template <typename T> struct Lowest;
+template <> struct Lowest<float>  { static __device__ __forceinline__ float  v() { return -FLT_MAX; } };
+template <> struct Lowest<double> { static __device__ __forceinline__ double v() { return -DBL_MAX; } };
+template <typename T> struct IdPad;
+template <> struct IdPad<int>       { static __device__ __forceinline__ int       v() { return INT_MAX; } };
+template <> struct IdPad<long long> { static __device__ __forceinline__ long long v() { return LLONG_MAX; } };
+
+template <typename KeyT, typename IdT, int KS>
+struct WaveTopK {
+    KeyT key[KS];
+    IdT id[KS];
+
+    static __device__ __forceinline__ bool ahead(KeyT ka, IdT ia, KeyT kb, IdT ib) {
+        return (ka > kb) || (ka == kb && ia < ib);
+    }
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            key[s] = Lowest<KeyT>::v();
+            id[s] = IdPad<IdT>::v();
+        }
+    }
+
+    // Wave-uniform (nk, ni).  All 64 lanes must call.
+    __device__ __forceinline__ void insert(KeyT nk, IdT ni, int lane) {
+        int pos = 0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pos += __popcll(__ballot(ahead(key[s], id[s], nk, ni)));
+#pragma unroll
+        for (int s = KS - 1; s >= 0; --s) {
+            KeyT uk = __shfl_up(key[s], 1);
+            IdT ui = __shfl_up(id[s], 1);
+            if (s > 0) {
+                KeyT ck = __shfl(key[s - 1], 63);
+                IdT ci = __shfl(id[s - 1], 63);
+                if (lane == 0) {
+                    uk = ck;
+                    ui = ci;
+                }
+            }
+            const int p = s * 64 + lane;
+            if (p > pos) {
+                key[s] = uk;
+                id[s] = ui;
+            } else if (p == pos) {
+                key[s] = nk;
+                id[s] = ni;
+            }
+        }
+    }
+
+    // (key, id) at list position k-1, broadcast to every lane.
+    __device__ __forceinline__ void kth(int k, KeyT& tk, IdT& ti) const {
+        const int p = k - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (s == (p >> 6)) {
+                tk = __shfl(key[s], p & 63);
+                ti = __shfl(id[s], p & 63);
+            }
+    }
+};
+
+// Each lane offers one candidate (ck, ci) (valid = false: none).  Candidates that rank
+// ahead of the current k-th entry are inserted in lane order.  thr_* track the k-th entry.
+template <typename KeyT, typename IdT, int KS>
+__device__ __forceinline__ void wave_offer(WaveTopK<KeyT, IdT, KS>& tk, int k, KeyT& thr_k, IdT& thr_i,
+                                           KeyT ck, IdT ci, bool valid, int lane) {
+    using TK = WaveTopK<KeyT, IdT, KS>;
+    unsigned long long m = __ballot(valid && TK::ahead(ck, ci, thr_k, thr_i));
+    while (m) {
+        const int l = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const KeyT nk = __shfl(ck, l);
+        const IdT ni = __shfl(ci, l);
+        if (TK::ahead(nk, ni, thr_k, thr_i)) {
+            tk.insert(nk, ni, lane);
+            tk.kth(k, thr_k, thr_i);
+        }
+    }
+}
+
+// Sum N = 2^LOGN per-lane values across the wave at once.  Returns, in every lane, the
+// wave-wide total of item (lane >> (6-LOGN)); costs N-1 select/shuffle/add steps plus
+// 6-LOGN plain butterfly steps instead of 6*N.  Summation order is fixed (deterministic).
+template <int N>
+__device__ __forceinline__ float wave_multi_reduce(float (&v)[N], int lane) {
+    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two <= 64");
+    int dist = 32;
+#pragma unroll
+    for (int half = N / 2; half >= 1; half >>= 1) {
+        const bool upper = (lane & dist) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float keep = upper ? v[i + half] : v[i];
+            const float send = upper ? v[i] : v[i + half];
+            v[i] = keep + __shfl_xor(send, dist);
+        }
+        dist >>= 1;
+    }
+    for (; dist >= 1; dist >>= 1) v[0] += __shfl_xor(v[0], dist);
+    return v[0];
+}
+
+// Block-wide merge of C candidate (key, id) pairs into one sorted k-list held by wave 0 of a
+// block of NWAVES waves.  `load(c, key, id)` returns the validity of candidate c in [0, C).
+// mk / mi: LDS scratch of (NWAVES-1)*KS*64 entries each.  Every thread of the block must call.
+template <typename KeyT, typename IdT, int KS, int NWAVES, class Loader>
+__device__ __forceinline__ void block_merge(Loader load, long long C, int k, WaveTopK<KeyT, IdT, KS>& tk,
+                                            KeyT* mk, IdT* mi) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    KeyT thr_k = Lowest<KeyT>::v();
+    IdT thr_i = IdPad<IdT>::v();
+    tk.init();
+    for (long long base = (long long)wid * 64; base < C; base += NWAVES * 64) {
+        const long long c = base + lane;
+        KeyT ck = Lowest<KeyT>::v();
+        IdT ci = IdPad<IdT>::v();
+        bool valid = false;
+        if (c < C) valid = load(c, ck, ci);
+        wave_offer<KeyT, IdT, KS>(tk, k, thr_k, thr_i, ck, ci, valid, lane);
+    }
+    if (wid > 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int o = ((wid - 1) * KS + s) * 64 + lane;
+            mk[o] = tk.key[s];
+            mi[o] = tk.id[s];
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+        for (int w = 0; w < NWAVES - 1; ++w)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int o = (w * KS + s) * 64 + lane;
+                wave_offer<KeyT, IdT, KS>(tk, k, thr_k, thr_i, mk[o], mi[o], true, lane);
+            }
+    }
+}
+
+template <int N> struct Log2 { static constexpr int v = 1 + Log2<N / 2>::v; };
+template <> struct Log2<1> { static constexpr int v = 0; };
+
+}  // namespace rag

@@ -1,0 +1,195 @@
+"""The slice of the faiss Python API that RAG-system uses, served by the MI355X engine.
+
+Reference call sites (vector_storage.py): faiss.IndexFlatIP(d) :79,:146,:151; index.add(x)
+:105,:152; index.search(x, k) :196; index.ntotal :193; faiss.write_index :231;
+faiss.read_index :298.  IndexFlatL2 is named by BASELINE.json's north_star.
+
+`import rag_system_amd.faiss_compat as faiss` is the whole integration.
+
+The numeric work happens in librag_mi355x.so (HIP, gfx950).  There is no CPU fallback:
+constructing an index without the library or without a GPU raises EngineUnavailable.
+`set_backend_factory` exists so that host-logic tests can inject the CPU oracle; nothing in
+the product calls it.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import _lib
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+
+
+class _HipFlatBackend:
+    """rag_flat_t handle (include/rag_mi355x.h)."""
+
+    def __init__(self, d, metric):
+        self._lib = _lib.engine()
+        h = C.c_void_p()
+        _lib.check(self._lib.rag_flat_create(int(d), int(metric), _lib.DTYPE_F32, C.byref(h)), self._lib)
+        self._h = h
+        self.d = int(d)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.rag_flat_free(h)
+            except Exception:
+                pass
+
+    @property
+    def ntotal(self):
+        return int(self._lib.rag_flat_ntotal(self._h))
+
+    def add(self, x):
+        _lib.check(self._lib.rag_flat_add(self._h, x.shape[0], _lib.ptr(x)), self._lib)
+
+    def add_synthetic(self, n, seed, first_global_row):
+        _lib.check(self._lib.rag_flat_add_synthetic(self._h, int(n), int(seed), int(first_global_row)), self._lib)
+
+    def reserve(self, n):
+        _lib.check(self._lib.rag_flat_reserve(self._h, int(n)), self._lib)
+
+    def search(self, q, k):
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self._lib.rag_flat_search(self._h, nq, _lib.ptr(q), int(k), _lib.ptr(D), _lib.ptr(I)), self._lib)
+        return D, I
+
+    def search_dev(self, nq, q_dev, k, D_dev, I_dev, id_base=0, stream=None):
+        _lib.check(self._lib.rag_flat_search_dev(self._h, int(nq), C.c_void_p(q_dev), int(k), C.c_void_p(D_dev),
+                                                 C.c_void_p(I_dev), int(id_base),
+                                                 C.c_void_p(stream) if stream else None), self._lib)
+
+    def reset(self):
+        _lib.check(self._lib.rag_flat_reset(self._h), self._lib)
+
+    def to_host(self, first=0, n=None):
+        n = self.ntotal - first if n is None else n
+        out = np.empty((n, self.d), dtype=np.float32)
+        _lib.check(self._lib.rag_flat_copy_to_host(self._h, int(first), int(n), _lib.ptr(out)), self._lib)
+        return out
+
+    def profiling(self, enable):
+        _lib.check(self._lib.rag_flat_profiling(self._h, 1 if enable else 0), self._lib)
+
+    def timing(self):
+        n = C.c_int64()
+        ms = C.c_double()
+        b = C.c_double()
+        _lib.check(self._lib.rag_flat_timing(self._h, C.byref(n), C.byref(ms), C.byref(b)), self._lib)
+        return n.value, ms.value, b.value
+
+
+_backend_factory = _HipFlatBackend
+
+
+def set_backend_factory(factory):
+    """Test seam: factory(d, metric) -> backend.  None restores the HIP engine."""
+    global _backend_factory
+    _backend_factory = factory or _HipFlatBackend
+
+
+class IndexFlat:
+    """faiss.IndexFlat: exact search over raw float32 vectors."""
+
+    def __init__(self, d, metric=METRIC_INNER_PRODUCT):
+        if int(d) <= 0:
+            raise ValueError("d must be positive")
+        self.d = int(d)
+        self.metric_type = int(metric)
+        self.is_trained = True
+        self._b = _backend_factory(self.d, self.metric_type)
+
+    @property
+    def ntotal(self):
+        return self._b.ntotal
+
+    def add(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError("add expects a (n, %d) float32 array, got %s" % (self.d, x.shape))
+        if x.shape[0]:
+            self._b.add(x)
+
+    def search(self, x, k):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError("search expects a (nq, %d) float32 array, got %s" % (self.d, x.shape))
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        if x.shape[0] == 0:
+            return np.empty((0, k), dtype=np.float32), np.empty((0, k), dtype=np.int64)
+        return self._b.search(x, k)
+
+    def reset(self):
+        self._b.reset()
+
+    def reconstruct_n(self, n0=0, ni=None):
+        return self._b.to_host(n0, ni)
+
+
+class IndexFlatIP(IndexFlat):
+    def __init__(self, d):
+        super().__init__(d, METRIC_INNER_PRODUCT)
+
+
+class IndexFlatL2(IndexFlat):
+    def __init__(self, d):
+        super().__init__(d, METRIC_L2)
+
+
+# ---- index.faiss codec (flat indexes) ----------------------------------------------------
+# faiss index_write.cpp / index_read.cpp, little-endian, no padding [published format;
+# un-verified against a faiss-written file in this environment -- SURVEY 8(b) b3]:
+#   char[4] fourcc "IxFI" (IP) | "IxF2" (L2);  int32 d;  int64 ntotal;  int64 dummy = 1<<20;
+#   int64 dummy = 1<<20;  uint8 is_trained;  int32 metric_type (0 IP, 1 L2);
+#   uint64 count = ntotal*d;  count x float32 (row-major).
+_HDR = struct.Struct("<4siqqqBi")  # 4+4+8+8+8+1+4 = 37 bytes, then uint64 size
+_FOURCC = {METRIC_INNER_PRODUCT: b"IxFI", METRIC_L2: b"IxF2"}
+
+
+def write_index(index, path):
+    if not isinstance(index, IndexFlat):
+        raise TypeError("write_index supports flat indexes only")
+    n = index.ntotal
+    with open(path, "wb") as f:
+        f.write(_HDR.pack(_FOURCC[index.metric_type], index.d, n, 1 << 20, 1 << 20, 1, index.metric_type))
+        f.write(struct.pack("<Q", n * index.d))
+        step = max(1, (64 << 20) // (4 * index.d))
+        for first in range(0, n, step):
+            cnt = min(step, n - first)
+            f.write(index.reconstruct_n(first, cnt).astype("<f4", copy=False).tobytes())
+
+
+def read_index(path):
+    with open(path, "rb") as f:
+        hdr = f.read(_HDR.size)
+        if len(hdr) != _HDR.size:
+            raise ValueError("%s: truncated faiss index header" % path)
+        fourcc, d, ntotal, _d1, _d2, _trained, metric = _HDR.unpack(hdr)
+        if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):
+            raise ValueError("%s: index type %r is not a flat index" % (path, fourcc))
+        if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
+            raise ValueError("%s: unsupported metric_type %d" % (path, metric))
+        if fourcc == b"IxFI" and metric != METRIC_INNER_PRODUCT or fourcc == b"IxF2" and metric != METRIC_L2:
+            raise ValueError("%s: fourcc %r contradicts metric_type %d" % (path, fourcc, metric))
+        (count,) = struct.unpack("<Q", f.read(8))
+        if count != ntotal * d:
+            raise ValueError("%s: vector payload size %d != ntotal*d = %d" % (path, count, ntotal * d))
+        index = IndexFlat(d, metric)
+        step = max(1, (64 << 20) // (4 * d))
+        left = ntotal
+        while left > 0:
+            cnt = min(step, left)
+            buf = f.read(cnt * d * 4)
+            if len(buf) != cnt * d * 4:
+                raise ValueError("%s: truncated vector payload" % path)
+            index.add(np.frombuffer(buf, dtype="<f4").reshape(cnt, d))
+            left -= cnt
+    return index
