@@ -18,7 +18,6 @@ the kernel runs on) and `cpu_baseline` (oracle/flat_ref.c:flat_search_cpu_baseli
 faiss-cpu-style fp32 scan, rank 0 at N=1 only, on a bounded sample of the same workload).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -98,6 +97,7 @@ def main():
     import torch
     import torch.distributed as dist
     from rag_system_amd import _lib, faiss_compat as faiss
+    from rag_system_amd.sharded import ShardedFlatSearcher
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -123,28 +123,18 @@ def main():
     del qgen
 
     q_dev = torch.from_numpy(Q).to(dev)
-    D_loc = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    I_loc = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    if world > 1:
-        D_all = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-        I_all = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
-        D_out = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        I_out = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    else:
-        D_out, I_out = D_loc, I_loc
-    D_host = torch.empty((nq, k), dtype=torch.float32).pin_memory()
-    I_host = torch.empty((nq, k), dtype=torch.int64).pin_memory()
     stream = torch.cuda.current_stream()
     st = stream.cuda_stream
 
+    def local_search(q, kk, D_loc, I_loc):
+        index._b.search_dev(nq, q.data_ptr(), kk, D_loc.data_ptr(), I_loc.data_ptr(), base, st)
+
+    searcher = ShardedFlatSearcher(local_search, 0, nq, k, dev, stream=st)
+    D_host = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+    I_host = torch.empty((nq, k), dtype=torch.int64).pin_memory()
+
     def step():
-        index._b.search_dev(nq, q_dev.data_ptr(), k, D_loc.data_ptr(), I_loc.data_ptr(), base, st)
-        if world > 1:
-            dist.all_gather_into_tensor(D_all, D_loc)
-            dist.all_gather_into_tensor(I_all, I_loc)
-            _lib.check(lib.rag_topk_merge_dev(0, world, nq, k, C.c_void_p(D_all.data_ptr()),
-                                              C.c_void_p(I_all.data_ptr()), C.c_void_p(D_out.data_ptr()),
-                                              C.c_void_p(I_out.data_ptr()), C.c_void_p(st)))
+        D_out, I_out = searcher.search(q_dev)
         D_host.copy_(D_out, non_blocking=True)
         I_host.copy_(I_out, non_blocking=True)
         stream.synchronize()

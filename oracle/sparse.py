@@ -1,0 +1,96 @@
+"""CPU restatement of the sparse scoring path -- TEST INFRASTRUCTURE ONLY (oracle/__init__.py).
+
+BM25: the arithmetic lives in rank_bm25 (unpinned, requirements.txt:12, absent here; its
+API and formula are those of rank_bm25 0.2.x).  The reference holds no fixture for it:
+PARITY UNPINNED.  The class below restates the published algorithm of
+rank_bm25.BM25 / BM25Okapi line by line (pure Python + numpy, float64), as called at
+vector_storage.py:170 (BM25Okapi(corpus, k1, b)), :305 (defaults k1=1.5, b=0.75,
+epsilon=0.25) and :178 (get_scores).
+
+TF-IDF: scikit-learn IS importable here, so the oracle is the real thing:
+TfidfVectorizer().fit_transform (vector_storage.py:216-217), vectorizer.transform and
+sklearn.metrics.pairwise.cosine_similarity (search_engine.py:284-285, 330-331).  Golden
+fixtures made with it are committed under tests/golden/ (tests/golden/make_tfidf_golden.py).
+"""
+import math
+
+import numpy as np
+
+
+class BM25OkapiRef:
+    """rank_bm25.BM25Okapi restated (0.2.x)."""
+
+    def __init__(self, corpus, k1=1.5, b=0.75, epsilon=0.25):
+        self.k1 = k1
+        self.b = b
+        self.epsilon = epsilon
+        self.corpus_size = 0
+        self.avgdl = 0
+        self.doc_freqs = []
+        self.idf = {}
+        self.doc_len = []
+        nd = self._initialize(corpus)
+        self._calc_idf(nd)
+
+    def _initialize(self, corpus):
+        nd = {}
+        num_doc = 0
+        for document in corpus:
+            self.doc_len.append(len(document))
+            num_doc += len(document)
+            frequencies = {}
+            for word in document:
+                if word not in frequencies:
+                    frequencies[word] = 0
+                frequencies[word] += 1
+            self.doc_freqs.append(frequencies)
+            for word, _freq in frequencies.items():
+                try:
+                    nd[word] += 1
+                except KeyError:
+                    nd[word] = 1
+            self.corpus_size += 1
+        self.avgdl = num_doc / self.corpus_size
+        return nd
+
+    def _calc_idf(self, nd):
+        idf_sum = 0
+        negative_idfs = []
+        for word, freq in nd.items():
+            idf = math.log(self.corpus_size - freq + 0.5) - math.log(freq + 0.5)
+            self.idf[word] = idf
+            idf_sum += idf
+            if idf < 0:
+                negative_idfs.append(word)
+        self.average_idf = idf_sum / len(self.idf)
+        eps = self.epsilon * self.average_idf
+        for word in negative_idfs:
+            self.idf[word] = eps
+
+    def get_scores(self, query):
+        score = np.zeros(self.corpus_size)
+        doc_len = np.array(self.doc_len)
+        for q in query:
+            q_freq = np.array([(doc.get(q) or 0) for doc in self.doc_freqs])
+            score += (self.idf.get(q) or 0) * (q_freq * (self.k1 + 1) /
+                                               (q_freq + self.k1 * (1 - self.b + self.b * doc_len / self.avgdl)))
+        return score
+
+
+def stable_topk_desc(scores, k):
+    """vector_storage.py:180: sorted(range(n), key=lambda i: scores[i], reverse=True)[:k]."""
+    return sorted(range(len(scores)), key=lambda i: scores[i], reverse=True)[:k]
+
+
+def stable_ranks_desc(scores):
+    """rank[i] = position of i in the stable descending sort (search_engine.py:332-336)."""
+    order = sorted(range(len(scores)), key=lambda i: scores[i], reverse=True)
+    ranks = np.empty(len(scores), dtype=np.int64)
+    ranks[order] = np.arange(len(scores))
+    return ranks
+
+
+def tfidf_cosine(vectorizer, matrix, query):
+    """search_engine.py:284-285: cosine_similarity(vectorizer.transform([query]), matrix)[0]."""
+    from sklearn.metrics.pairwise import cosine_similarity
+    return cosine_similarity(vectorizer.transform([query]), matrix)[0]

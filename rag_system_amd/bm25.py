@@ -1,0 +1,210 @@
+"""BM25Okapi with rank_bm25's API, scored on the MI355X.
+
+Reference call sites: BM25Okapi(corpus, k1=, b=) vector_storage.py:170, BM25Okapi(corpus)
+:305 (library defaults k1=1.5, b=0.75, epsilon=0.25), bm25.get_scores(tokens) :178 followed by
+the full stable descending sort of :180.
+
+The index statistics (vocabulary, term frequencies, idf with the epsilon floor, avgdl) are
+built on the host exactly as rank_bm25 builds them; the postings are uploaded once as a
+term-major (CSC) matrix; get_scores / top_k run rag_bm25_scores (csrc/sparse.hip).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+
+class _HipCsc:
+    """rag_csc_t handle (include/rag_mi355x.h)."""
+
+    def __init__(self, n_terms, n_rows, indptr, rows, vals):
+        self._lib = _lib.engine()
+        self.n_terms, self.n_rows = int(n_terms), int(n_rows)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        h = C.c_void_p()
+        _lib.check(self._lib.rag_csc_create(self.n_terms, self.n_rows, _lib.ptr(indptr), _lib.ptr(rows),
+                                            _lib.ptr(vals), C.byref(h)), self._lib)
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.rag_csc_free(h)
+            except Exception:
+                pass
+
+    def bm25_set(self, idf, doc_len, avgdl, k1, b):
+        idf = np.ascontiguousarray(idf, dtype=np.float64)
+        doc_len = np.ascontiguousarray(doc_len, dtype=np.int32)
+        _lib.check(self._lib.rag_bm25_set(self._h, _lib.ptr(idf), _lib.ptr(doc_len), float(avgdl), float(k1),
+                                          float(b)), self._lib)
+
+    def _out(self, want_scores, k):
+        scores = np.empty(self.n_rows, dtype=np.float64) if want_scores else None
+        D = np.empty(max(k, 1), dtype=np.float64)
+        I = np.empty(max(k, 1), dtype=np.int64)
+        return scores, D, I
+
+    def bm25_scores(self, term_ids, want_scores=True, k=0):
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        scores, D, I = self._out(want_scores, k)
+        _lib.check(self._lib.rag_bm25_scores(self._h, len(t), _lib.ptr(t), _lib.ptr(scores), int(k), _lib.ptr(D),
+                                             _lib.ptr(I)), self._lib)
+        return scores, D[:k], I[:k]
+
+    def tfidf_scores(self, term_ids, weights, want_scores=True, k=0):
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        scores, D, I = self._out(want_scores, k)
+        _lib.check(self._lib.rag_tfidf_scores(self._h, len(t), _lib.ptr(t), _lib.ptr(w), _lib.ptr(scores), int(k),
+                                              _lib.ptr(D), _lib.ptr(I)), self._lib)
+        return scores, D[:k], I[:k]
+
+    def ranks(self, rows):
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty(len(r), dtype=np.int64)
+        _lib.check(self._lib.rag_csc_ranks(self._h, len(r), _lib.ptr(r), _lib.ptr(out)), self._lib)
+        return out
+
+
+_csc_factory = _HipCsc
+
+
+def set_csc_factory(factory):
+    """Test seam (host-logic tests inject the CPU oracle); None restores the HIP engine."""
+    global _csc_factory
+    _csc_factory = factory or _HipCsc
+
+
+def make_csc(n_terms, n_rows, indptr, rows, vals):
+    return _csc_factory(n_terms, n_rows, indptr, rows, vals)
+
+
+class BM25Okapi:
+    """rank_bm25.BM25Okapi(corpus, tokenizer=None, k1=1.5, b=0.75, epsilon=0.25)."""
+
+    MAX_FUSED_K = _lib.MAX_K
+
+    def __init__(self, corpus, tokenizer=None, k1=1.5, b=0.75, epsilon=0.25):
+        self.k1 = k1
+        self.b = b
+        self.epsilon = epsilon
+        self.tokenizer = tokenizer
+        if tokenizer:
+            corpus = [tokenizer(doc) for doc in corpus]
+        self.corpus_size = 0
+        self.avgdl = 0
+        self.doc_len = []
+        self.idf = {}
+        self._vocab = {}          # word -> term id, in first-appearance order (= nd order)
+        post_rows = []            # per term: list of doc ids (ascending)
+        post_tf = []
+        num_doc = 0
+        for di, document in enumerate(corpus):
+            self.doc_len.append(len(document))
+            num_doc += len(document)
+            frequencies = {}
+            for word in document:
+                frequencies[word] = frequencies.get(word, 0) + 1
+            for word, freq in frequencies.items():
+                t = self._vocab.get(word)
+                if t is None:
+                    t = len(self._vocab)
+                    self._vocab[word] = t
+                    post_rows.append([])
+                    post_tf.append([])
+                post_rows[t].append(di)
+                post_tf[t].append(freq)
+            self.corpus_size += 1
+        if self.corpus_size == 0:
+            raise ZeroDivisionError("division by zero")  # rank_bm25: num_doc / corpus_size
+        self.avgdl = num_doc / self.corpus_size
+        df = np.fromiter((len(r) for r in post_rows), dtype=np.int64, count=len(post_rows))
+        self._finish(df,
+                     np.concatenate([np.zeros(1, np.int64), np.cumsum(df)]),
+                     np.fromiter((d for r in post_rows for d in r), dtype=np.int32, count=int(df.sum())),
+                     np.fromiter((f for r in post_tf for f in r), dtype=np.float64, count=int(df.sum())))
+
+    @classmethod
+    def from_term_ids(cls, doc_indptr, doc_terms, k1=1.5, b=0.75, epsilon=0.25):
+        """Corpus given as integer tokens: document i = doc_terms[doc_indptr[i]:doc_indptr[i+1]].
+        Same statistics as the list-of-tokens constructor (token = the integer), built with
+        numpy so that million-document synthetic corpora index in seconds."""
+        self = cls.__new__(cls)
+        self.k1, self.b, self.epsilon, self.tokenizer = k1, b, epsilon, None
+        doc_indptr = np.asarray(doc_indptr, dtype=np.int64)
+        doc_terms = np.asarray(doc_terms, dtype=np.int64)
+        n = len(doc_indptr) - 1
+        if n <= 0:
+            raise ZeroDivisionError("division by zero")
+        self.corpus_size = n
+        lens = np.diff(doc_indptr)
+        self.doc_len = lens.tolist()
+        self.avgdl = int(lens.sum()) / n
+        doc_of = np.repeat(np.arange(n, dtype=np.int64), lens)
+        # vocabulary in first-appearance order
+        uniq, first_pos = np.unique(doc_terms, return_index=True)
+        order = np.argsort(first_pos, kind="stable")
+        tid_of_uniq = np.empty(len(uniq), dtype=np.int64)
+        tid_of_uniq[order] = np.arange(len(uniq))
+        tids = tid_of_uniq[np.searchsorted(uniq, doc_terms)]
+        self._vocab = {int(w): int(t) for w, t in zip(uniq[order], range(len(uniq)))}
+        # (term, doc) pairs -> term frequencies
+        key = tids * n + doc_of
+        ukey, tf = np.unique(key, return_counts=True)
+        p_term = ukey // n
+        p_doc = (ukey - p_term * n).astype(np.int32)
+        df = np.bincount(p_term, minlength=len(uniq)).astype(np.int64)
+        self.idf = {}
+        self._finish(df, np.concatenate([np.zeros(1, np.int64), np.cumsum(df)]), p_doc, tf.astype(np.float64))
+        return self
+
+    def _finish(self, df, indptr, rows, tf):
+        n = self.corpus_size
+        words = list(self._vocab.keys())
+        idf = np.empty(len(words), dtype=np.float64)
+        idf_sum = 0
+        negative = []
+        for t in range(len(words)):
+            freq = int(df[t])
+            v = math.log(n - freq + 0.5) - math.log(freq + 0.5)
+            idf[t] = v
+            idf_sum += v
+            if v < 0:
+                negative.append(t)
+        self.average_idf = idf_sum / len(words)   # ZeroDivisionError on an empty vocabulary, as rank_bm25
+        eps = self.epsilon * self.average_idf
+        for t in negative:
+            idf[t] = eps
+        self.idf = {w: float(idf[t]) for t, w in enumerate(words)}
+        self._idf_arr = idf
+        self._csc = make_csc(len(words), n, indptr, rows, tf)
+        self._csc.bm25_set(idf, np.asarray(self.doc_len, dtype=np.int32), self.avgdl, self.k1, self.b)
+
+    def _term_ids(self, query):
+        # out-of-vocabulary tokens add (idf.get(q) or 0) * 0 = 0: dropped.  Repeats stay.
+        v = self._vocab
+        return [v[q] for q in query if q in v]
+
+    def get_scores(self, query):
+        """np.float64 (corpus_size,) -- rank_bm25.BM25Okapi.get_scores."""
+        scores, _, _ = self._csc.bm25_scores(self._term_ids(query), want_scores=True, k=0)
+        return scores
+
+    def top_k(self, query, k):
+        """(ids, scores) of the first k entries of sorted(range(n), key=scores, reverse=True)
+        (vector_storage.py:180) without materialising the score vector on the host."""
+        k = min(int(k), self.corpus_size)
+        if k <= 0:
+            return np.empty(0, np.int64), np.empty(0, np.float64)
+        if k > self.MAX_FUSED_K:
+            scores = self.get_scores(query)
+            ids = np.array(sorted(range(len(scores)), key=lambda i: scores[i], reverse=True)[:k], dtype=np.int64)
+            return ids, scores[ids]
+        _, D, I = self._csc.bm25_scores(self._term_ids(query), want_scores=False, k=k)
+        return I, D

@@ -1,0 +1,72 @@
+"""TF-IDF cosine scoring on the MI355X.
+
+Reference call sites: search_engine.py:284-285 and :330-331
+    query_vec = tfidf_vectorizer.transform([query])
+    tfidf_scores = cosine_similarity(query_vec, tfidf_matrix)[0]
+followed (rrf) by a stable descending sort of ALL documents (:332-336).
+
+The vocabulary / idf / matrix are built by scikit-learn's TfidfVectorizer exactly as the
+reference does (vector_storage.py:216-217) -- that is host-side index construction and
+stays in sklearn so tfidf.pkl remains interchangeable.  What moves to the GPU is the per-query
+product: cosine_similarity re-normalises both operands and multiplies q (1 x V) with M^T;
+here M is re-normalised ONCE at upload (sklearn.preprocessing.normalize, the same routine
+cosine_similarity calls), stored term-major in HBM, and each query runs rag_tfidf_scores
+(csrc/sparse.hip), which adds w_t * M[doc, t] term by term in scipy's order.
+"""
+import numpy as np
+
+from . import bm25 as _bm25
+
+
+class TfidfScorer:
+    def __init__(self, vectorizer, matrix):
+        from sklearn.preprocessing import normalize
+        self.vectorizer = vectorizer
+        self.n_docs, self.n_terms = matrix.shape
+        mn = normalize(matrix.tocsr(), copy=True)   # what cosine_similarity does to Y
+        csc = mn.tocsc()
+        csc.sort_indices()
+        self._csc = _bm25.make_csc(self.n_terms, self.n_docs, csc.indptr.astype(np.int64),
+                                   csc.indices.astype(np.int32), csc.data.astype(np.float64))
+
+    def _normalized(self, qv):
+        from sklearn.preprocessing import normalize
+        qn = normalize(qv, copy=True)               # what cosine_similarity does to X
+        qn.sort_indices()
+        return qn.indices.astype(np.int32), qn.data.astype(np.float64)
+
+    def _query(self, query):
+        return self._normalized(self.vectorizer.transform([query]))
+
+    def scores_from_row(self, indices, data):
+        """Scores for an already vectorised query row (the output of vectorizer.transform)."""
+        from scipy.sparse import csr_matrix
+        indices = np.asarray(indices, dtype=np.int32)
+        qv = csr_matrix((np.asarray(data, dtype=np.float64), indices, np.array([0, len(indices)], dtype=np.int32)),
+                        shape=(1, self.n_terms))
+        t, w = self._normalized(qv)
+        s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
+        return s
+
+    def scores(self, query):
+        """cosine_similarity(vectorizer.transform([query]), matrix)[0] as float64 (n_docs,)."""
+        t, w = self._query(query)
+        s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
+        return s
+
+    def top_k(self, query, k):
+        """First k (doc index, score) of the stable descending sort of all documents."""
+        k = min(int(k), self.n_docs)
+        t, w = self._query(query)
+        if k > _bm25.BM25Okapi.MAX_FUSED_K:
+            s = self.scores(query)
+            ids = np.array(sorted(range(len(s)), key=lambda i: s[i], reverse=True)[:k], dtype=np.int64)
+            return ids, s[ids]
+        _, D, I = self._csc.tfidf_scores(t, w, want_scores=False, k=k)
+        return I, D
+
+    def ranks(self, doc_indices):
+        """0-based rank of each document in the stable descending sort of the scores of the
+        LAST scores()/top_k() call (search_engine.py:332-336 sorts all documents; RRF only
+        needs the ranks of its candidates)."""
+        return self._csc.ranks(doc_indices)
