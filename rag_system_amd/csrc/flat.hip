@@ -15,6 +15,7 @@
 //   * the four waves of a block merge through LDS and write ONE k-list per block,
 //   * flat_merge_kernel (one block per query) merges the per-block lists.
 #include "common.h"
+#include "flat_mfma.h"
 #include "topk.h"
 
 #include <algorithm>
@@ -299,6 +300,9 @@ struct rag_flat {
     float* ws_q = nullptr;   int64_t ws_q_cap = 0;     // padded queries
     float* ws_key = nullptr; int64_t ws_key_cap = 0;
     int* ws_id = nullptr;    int64_t ws_id_cap = 0;
+    float* ws_qn = nullptr;  int64_t ws_qn_cap = 0;    // ||q||^2 (L2, MFMA path)
+    float* xnorm = nullptr;  int64_t xnorm_cap = 0;    // ||x||^2 per row (L2, MFMA path), lazily filled
+    int64_t norm_valid = 0;
     float* ws_hq = nullptr;  int64_t ws_hq_cap = 0;    // host-variant device copies
     float* ws_D = nullptr; long long* ws_I = nullptr; int64_t ws_out_cap = 0;
     // profiling
@@ -445,6 +449,58 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         RAG_HIP(hipGetLastError());
     }
 
+    MfmaPlan plan;
+    if (nq >= opt.mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, &plan)) {
+        rc = grow(h->ws_key, h->ws_key_cap, nq * plan.S * k);
+        if (rc) return rc;
+        rc = grow(h->ws_id, h->ws_id_cap, nq * plan.S * k);
+        if (rc) return rc;
+        if (h->metric == RAG_METRIC_L2) {
+            if (h->xnorm_cap < h->cap) {  // follow the arena
+                float* nn = nullptr;
+                RAG_HIP(hipMalloc(&nn, (size_t)h->cap * sizeof(float)));
+                if (h->norm_valid > 0)
+                    RAG_HIP(hipMemcpyAsync(nn, h->xnorm, (size_t)h->norm_valid * sizeof(float), hipMemcpyDeviceToDevice, st));
+                RAG_HIP(hipStreamSynchronize(st));
+                if (h->xnorm) RAG_HIP(hipFree(h->xnorm));
+                h->xnorm = nn;
+                h->xnorm_cap = h->cap;
+            }
+            if (h->norm_valid < n) {
+                rc = mfma_row_norms(h->x, ld, h->norm_valid, n - h->norm_valid, h->xnorm, st);
+                if (rc) return rc;
+                h->norm_valid = n;
+            }
+            rc = grow(h->ws_qn, h->ws_qn_cap, nq);
+            if (rc) return rc;
+            rc = mfma_row_norms(h->ws_q, ld, 0, nq, h->ws_qn, st);
+            if (rc) return rc;
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->prof) {
+            if (!h->ev_free.empty()) {
+                e0 = h->ev_free.back().first;
+                e1 = h->ev_free.back().second;
+                h->ev_free.pop_back();
+            } else {
+                RAG_HIP(hipEventCreate(&e0));
+                RAG_HIP(hipEventCreate(&e1));
+            }
+            RAG_HIP(hipEventRecord(e0, st));
+        }
+        rc = mfma_launch(plan, h->x, (long long)n, ld, h->ws_q, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                         h->ws_qn, st);
+        if (rc) return rc;
+        if (h->prof) {
+            RAG_HIP(hipEventRecord(e1, st));
+            h->ev_used.emplace_back(e0, e1);
+        }
+        merge_fn_t mf = pick_merge(KS, h->metric);
+        mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.S, k, D_dev, I_dev, (long long)id_base);
+        RAG_HIP(hipGetLastError());
+        return RAG_OK;
+    }
+
     int64_t blocks = opt.scan_blocks > 0 ? opt.scan_blocks : (int64_t)num_cus() * 4;
     int Rsel = (opt.scan_rows == 2 || opt.scan_rows == 8) ? (int)opt.scan_rows : 4;
 
@@ -531,6 +587,8 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_key);
         (void)hipFree(h->ws_id);
         (void)hipFree(h->ws_hq);
+        (void)hipFree(h->ws_qn);
+        (void)hipFree(h->xnorm);
         (void)hipFree(h->ws_D);
         (void)hipFree(h->ws_I);
         for (auto& p : h->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -620,6 +678,7 @@ int rag_flat_reset(rag_flat_t* h) {
     h->staged.clear();
     h->ntotal = 0;
     h->ndev = 0;
+    h->norm_valid = 0;
     return RAG_OK;
 }
 

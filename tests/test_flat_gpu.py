@@ -267,3 +267,38 @@ def test_full_size_10M_x_384_against_streaming_oracle(engine):
         return rows.astype(np.float64) @ Q[qi].astype(np.float64)
     od.check_topk(D, I, Dm.astype(np.float64), Im, RTOL, ATOL, scorer)
     assert I[2, 0] == 0 and I[2, 1] == n, "duplicate of row 0 must follow it (lower id first)"
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d", [(1, 384), (300, 384), (4099, 768), (3001, 37), (20_011, 384), (1000, 20)])
+def test_batched_mfma_search_matches_oracle(engine, n, d, metric):
+    """nq >= 5 goes through the f32 MFMA tile kernel (flat_mfma.hip) for k <= 64."""
+    rng = np.random.default_rng(n * 7 + d + metric)
+    X = _rand_unit(rng, n, d)
+    if n > 100:
+        X[n // 2] = X[3]          # exact duplicates inside and across row tiles
+        X[n - 1] = X[3]
+    idx = _index(d, metric)
+    idx.add(X)
+    for nq, k in [(5, 10), (19, 1), (33, 32), (64, 10), (100, 33), (256, 10), (300, 64), (1024, 10), (7, 90)]:
+        Q = _rand_unit(rng, nq, d)
+        Q[0] = X[min(3, n - 1)]   # a query equal to a (duplicated) row
+        D, I = idx.search(Q, k)
+        _, Ir, D64 = od.flat_search(X, Q, k, metric)
+        # L2 in the MFMA path is ||x||^2 + ||q||^2 - 2<x,q> (what faiss does for nq >= 20):
+        # absolute error ~1e-7 * (||x||^2 + ||q||^2), so near-zero distances need an absolute floor
+        atol = ATOL if metric == 0 else 2e-6
+        od.check_topk(D, I, D64, Ir, RTOL, atol, _scorer(X, Q, metric))
+
+
+def test_batched_results_identical_to_single_queries_ids(engine):
+    rng = np.random.default_rng(77)
+    X = _rand_unit(rng, 30_000, 384)
+    Q = _rand_unit(rng, 64, 384)
+    idx = _index(384)
+    idx.add(X)
+    Db, Ib = idx.search(Q, 10)
+    for qi in (0, 17, 63):
+        D1, I1 = idx.search(Q[qi:qi + 1], 10)
+        assert np.array_equal(I1[0], Ib[qi])
+        assert np.allclose(D1[0], Db[qi], rtol=1e-5, atol=1e-6)
