@@ -177,7 +177,7 @@ def main():
             ach = flops / (avg_scan_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None}
-        roof.update({"kernel": "flat_scan_kernel", "avg_launch_ms": avg_scan_ms, "launches": n_launch,
+        roof.update({"kernel": "flat_scan_kernel" if nq < 5 else "flat_mfma_kernel", "avg_launch_ms": avg_scan_ms, "launches": n_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch})
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1:

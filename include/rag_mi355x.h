@@ -44,9 +44,12 @@ extern "C" {
 #define RAG_DTYPE_F32  0  /* rows stored as float32 (faiss IndexFlat)      */
 #define RAG_DTYPE_BF16 1  /* rows stored as bfloat16 (RNE), fp32 accumulate */
 
-/* Largest k the fused scan+select kernels serve (faiss-gpu's own limit is
- * 2048; the reference issues k in {top_k, 3*top_k, 9*top_k} = {10,30,90}). */
+/* Largest k one fused scan+select pass serves; larger k (up to RAG_MAX_K_TOTAL) is served in
+ * ceil(k/256) passes over the matrix.  (faiss-gpu's own limit is 2048; the reference issues
+ * k in {top_k, 3*top_k, 9*top_k} = {10,30,90} at its default top_k.)  rag_topk_merge_dev and
+ * the sparse top-k accept k <= RAG_MAX_K. */
 #define RAG_MAX_K 256
+#define RAG_MAX_K_TOTAL 16384
 
 typedef struct rag_flat rag_flat_t;
 typedef struct rag_csc  rag_csc_t;
@@ -92,7 +95,7 @@ int rag_flat_reset(rag_flat_t* h);
  * q: nq*d float32; D: nq*k float32; I: nq*k int64, best first.
  * IP: descending inner product; L2: ascending squared distance.
  * Ties: lower id first.  k > ntotal: tail padded with I=-1 and
- * D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= RAG_MAX_K. */
+ * D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= RAG_MAX_K_TOTAL. */
 int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I);
 /* Same, device-resident query and outputs, asynchronous on `stream`;
  * returned ids are id_base + local row (id_base = first global row of this
@@ -151,6 +154,10 @@ int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const dou
  * vector computed on this handle) of each of n_query rows: search_engine.py
  * :332-336 sorts ALL documents; RRF needs 1/(60+rank) only for candidates. */
 int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks);
+/* Scores of n_query rows out of the LAST score vector computed on this handle:
+ * search_engine.py:286 builds a dict over ALL documents, of which the fusion
+ * (:301-311) only reads the candidates' entries. */
+int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_scores);
 
 /* ---- candidate-set kernels -------------------------------------------- */
 

@@ -72,6 +72,13 @@ class _HipCsc:
         return out
 
 
+    def gather(self, rows):
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty(len(r), dtype=np.float64)
+        _lib.check(self._lib.rag_csc_gather(self._h, len(r), _lib.ptr(r), _lib.ptr(out)), self._lib)
+        return out
+
+
 _csc_factory = _HipCsc
 
 

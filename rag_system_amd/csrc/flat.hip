@@ -54,7 +54,8 @@ __device__ __forceinline__ float dot4_acc(f32x4 x, f32x4 q, float acc) {
 template <int R, int NQ, int KS, int METRIC, bool NT>
 __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
     const f32x4* __restrict__ X4, long long n, int d4, const f32x4* __restrict__ Q4, int k,
-    float* __restrict__ cand_key, int* __restrict__ cand_id) {
+    float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ floor_key,
+    const int* __restrict__ floor_id) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     f32x4* q_lds = reinterpret_cast<f32x4*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -71,6 +72,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
         tk[q].init();
         thr_k[q] = Lowest<float>::v();
         thr_i[q] = IdPad<int>::v();
+    }
+    // k > 256 is served in passes: a later pass only admits rows that rank strictly behind the
+    // last entry of the previous pass (the "floor") of the same query.
+    const bool has_floor = floor_key != nullptr;
+    float fl_k[NQ];
+    int fl_i[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        fl_k[q] = has_floor ? floor_key[q] : 0.f;
+        fl_i[q] = has_floor ? floor_id[q] : 0;
     }
 
     constexpr int N = R * NQ;
@@ -114,9 +125,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
         const long long row = row0 + r_of;
         const float key = (METRIC == RAG_METRIC_IP) ? tot : -tot;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], key, (int)row,
-                                       rep && q_of == q && row < n, lane);
+        for (int q = 0; q < NQ; ++q) {
+            bool ok = rep && q_of == q && row < n;
+            if (has_floor) ok = ok && TK::ahead(fl_k[q], fl_i[q], key, (int)row);
+            wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], key, (int)row, ok, lane);
+        }
     }
 
     // ---- merge the block's four wave lists through LDS, wave 0 writes one list per query
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
 template <int KS, int METRIC>
 __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
     const float* __restrict__ cand_key, const int* __restrict__ cand_id, int nlists, int k,
-    float* __restrict__ D, long long* __restrict__ I, long long id_base) {
+    float* __restrict__ D, long long* __restrict__ I, long long id_base, int out_stride, int out_off) {
     __shared__ float mk[(MERGE_WAVES - 1) * KS * 64];
     __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
     const long long q = blockIdx.x;
@@ -185,9 +198,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
             if (p < k) {
                 const bool pad = tk.id[s] == IdPad<int>::v();
                 const float key = tk.key[s];
-                D[q * k + p] = pad ? (METRIC == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX)
-                                   : (METRIC == RAG_METRIC_IP ? key : -key);
-                I[q * k + p] = pad ? -1LL : id_base + (long long)tk.id[s];
+                const long long o = q * out_stride + out_off + p;
+                D[o] = pad ? (METRIC == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX) : (METRIC == RAG_METRIC_IP ? key : -key);
+                I[o] = pad ? -1LL : id_base + (long long)tk.id[s];
             }
         }
     }
@@ -226,6 +239,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
                 I[q * k + p] = pad ? -1LL : tk.id[s];
             }
         }
+    }
+}
+
+// floor of pass p+1 = last entry of pass p (position `pos` of each query's output row).
+__global__ void make_floor_kernel(const float* __restrict__ D, const long long* __restrict__ I, long long nq,
+                                  int stride, int pos, int metric, long long id_base, float* __restrict__ fk,
+                                  int* __restrict__ fi) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) {
+        const long long id = I[q * stride + pos];
+        const float d = D[q * stride + pos];
+        fk[q] = id < 0 ? Lowest<float>::v() : (metric == RAG_METRIC_IP ? d : -d);
+        fi[q] = id < 0 ? IdPad<int>::v() : (int)(id - id_base);
     }
 }
 
@@ -300,6 +326,8 @@ struct rag_flat {
     float* ws_q = nullptr;   int64_t ws_q_cap = 0;     // padded queries
     float* ws_key = nullptr; int64_t ws_key_cap = 0;
     int* ws_id = nullptr;    int64_t ws_id_cap = 0;
+    float* ws_fk = nullptr;  int64_t ws_fk_cap = 0;    // per-query floors for k > 256 passes
+    int* ws_fi = nullptr;    int64_t ws_fi_cap = 0;
     float* ws_qn = nullptr;  int64_t ws_qn_cap = 0;    // ||q||^2 (L2, MFMA path)
     float* xnorm = nullptr;  int64_t xnorm_cap = 0;    // ||x||^2 per row (L2, MFMA path), lazily filled
     int64_t norm_valid = 0;
@@ -384,7 +412,7 @@ struct ScanCfg {
     bool nt;
 };
 
-typedef void (*scan_fn_t)(const f32x4*, long long, int, const f32x4*, int, float*, int*);
+typedef void (*scan_fn_t)(const f32x4*, long long, int, const f32x4*, int, float*, int*, const float*, const int*);
 
 template <int R, int NQ, int KS>
 scan_fn_t pick_scan2(int metric, bool nt) {
@@ -410,7 +438,7 @@ scan_fn_t pick_scan(const ScanCfg& c) {
     return pick_scan1<4, 4>(c.KS, c.metric, c.nt);
 }
 
-typedef void (*merge_fn_t)(const float*, const int*, int, int, float*, long long*, long long);
+typedef void (*merge_fn_t)(const float*, const int*, int, int, float*, long long*, long long, int, int);
 merge_fn_t pick_merge(int KS, int metric) {
     if (metric == RAG_METRIC_IP) {
         if (KS == 1) return flat_merge_kernel<1, RAG_METRIC_IP>;
@@ -439,7 +467,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         return fail(RAG_ERR_UNSUPPORTED, "more than 2^31-9 rows in one shard (%lld)", (long long)n);
     const int ld = h->ld, d4 = ld / 4;
     const Options& opt = options();
-    const int KS = ks_for(k);
+    const int KS = ks_for(k > RAG_MAX_K ? RAG_MAX_K : k);
 
     int rc = grow(h->ws_q, h->ws_q_cap, nq * ld);
     if (rc) return rc;
@@ -496,7 +524,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             h->ev_used.emplace_back(e0, e1);
         }
         merge_fn_t mf = pick_merge(KS, h->metric);
-        mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.S, k, D_dev, I_dev, (long long)id_base);
+        mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.S, k, D_dev, I_dev, (long long)id_base, k, 0);
         RAG_HIP(hipGetLastError());
         return RAG_OK;
     }
@@ -504,51 +532,70 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     int64_t blocks = opt.scan_blocks > 0 ? opt.scan_blocks : (int64_t)num_cus() * 4;
     int Rsel = (opt.scan_rows == 2 || opt.scan_rows == 8) ? (int)opt.scan_rows : 4;
 
-    for (int64_t q0 = 0; q0 < nq;) {
-        const int64_t left = nq - q0;
-        const int NQ = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
-        const int R = NQ == 1 ? Rsel : 4;
-        const int64_t ntiles = (n + R - 1) / R;
-        int64_t nb = std::min<int64_t>(blocks, (ntiles + SCAN_WAVES - 1) / SCAN_WAVES);
-        nb = std::max<int64_t>(nb, 1);
-        rc = grow(h->ws_key, h->ws_key_cap, (int64_t)NQ * nb * k);
-        if (rc) return rc;
-        rc = grow(h->ws_id, h->ws_id_cap, (int64_t)NQ * nb * k);
-        if (rc) return rc;
-        const size_t qbytes = (size_t)(((int64_t)NQ * d4 * 16 + 15) & ~15LL);
-        const size_t smem = qbytes + (size_t)(SCAN_WAVES - 1) * NQ * KS * 64 * 8;
-        if (smem > 160 * 1024)
-            return fail(RAG_ERR_UNSUPPORTED, "d=%d too large for the LDS-resident query (%zu B)", h->d, smem);
-        ScanCfg cfg{R, NQ, KS, h->metric, opt.scan_nt != 0};
-        scan_fn_t fn = pick_scan(cfg);
-        if (smem > 48 * 1024)
-            RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->prof) {
-            if (!h->ev_free.empty()) {
-                e0 = h->ev_free.back().first;
-                e1 = h->ev_free.back().second;
-                h->ev_free.pop_back();
-            } else {
-                RAG_HIP(hipEventCreate(&e0));
-                RAG_HIP(hipEventCreate(&e1));
+    // k <= 256: one pass.  Larger k: passes of <= 256, each bounded by the previous pass' last entry.
+    for (int done = 0; done < k; done += RAG_MAX_K) {
+        const int kp = std::min(RAG_MAX_K, k - done);
+        const int KSp = ks_for(kp);
+        const float* fl_k = nullptr;
+        const int* fl_i = nullptr;
+        if (done > 0) {
+            rc = grow(h->ws_fk, h->ws_fk_cap, nq);
+            if (rc) return rc;
+            rc = grow(h->ws_fi, h->ws_fi_cap, nq);
+            if (rc) return rc;
+            make_floor_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, st>>>(D_dev, I_dev, nq, k, done - 1, h->metric,
+                                                                           (long long)id_base, h->ws_fk, h->ws_fi);
+            RAG_HIP(hipGetLastError());
+            fl_k = h->ws_fk;
+            fl_i = h->ws_fi;
+        }
+        for (int64_t q0 = 0; q0 < nq;) {
+            const int64_t left = nq - q0;
+            const int NQ = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+            const int R = NQ == 1 ? Rsel : 4;
+            const int64_t ntiles = (n + R - 1) / R;
+            int64_t nb = std::min<int64_t>(blocks, (ntiles + SCAN_WAVES - 1) / SCAN_WAVES);
+            nb = std::max<int64_t>(nb, 1);
+            rc = grow(h->ws_key, h->ws_key_cap, (int64_t)NQ * nb * kp);
+            if (rc) return rc;
+            rc = grow(h->ws_id, h->ws_id_cap, (int64_t)NQ * nb * kp);
+            if (rc) return rc;
+            const size_t qbytes = (size_t)(((int64_t)NQ * d4 * 16 + 15) & ~15LL);
+            const size_t smem = qbytes + (size_t)(SCAN_WAVES - 1) * NQ * KSp * 64 * 8;
+            if (smem > 160 * 1024)
+                return fail(RAG_ERR_UNSUPPORTED, "d=%d too large for the LDS-resident query (%zu B)", h->d, smem);
+            ScanCfg cfg{R, NQ, KSp, h->metric, opt.scan_nt != 0};
+            scan_fn_t fn = pick_scan(cfg);
+            if (smem > 48 * 1024)
+                RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->prof) {
+                if (!h->ev_free.empty()) {
+                    e0 = h->ev_free.back().first;
+                    e1 = h->ev_free.back().second;
+                    h->ev_free.pop_back();
+                } else {
+                    RAG_HIP(hipEventCreate(&e0));
+                    RAG_HIP(hipEventCreate(&e1));
+                }
+                RAG_HIP(hipEventRecord(e0, st));
             }
-            RAG_HIP(hipEventRecord(e0, st));
+            fn<<<(unsigned)nb, SCAN_THREADS, smem, st>>>(reinterpret_cast<const f32x4*>(h->x), (long long)n, d4,
+                                                        reinterpret_cast<const f32x4*>(h->ws_q + q0 * ld), kp,
+                                                        h->ws_key, h->ws_id, fl_k ? fl_k + q0 : nullptr,
+                                                        fl_i ? fl_i + q0 : nullptr);
+            RAG_HIP(hipGetLastError());
+            if (h->prof) {
+                RAG_HIP(hipEventRecord(e1, st));
+                h->ev_used.emplace_back(e0, e1);
+            }
+            merge_fn_t mf = pick_merge(KSp, h->metric);
+            mf<<<(unsigned)NQ, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, (int)nb, kp, D_dev + q0 * k,
+                                                       I_dev + q0 * k, (long long)id_base, k, done);
+            RAG_HIP(hipGetLastError());
+            q0 += NQ;
         }
-        fn<<<(unsigned)nb, SCAN_THREADS, smem, st>>>(reinterpret_cast<const f32x4*>(h->x), (long long)n, d4,
-                                                    reinterpret_cast<const f32x4*>(h->ws_q + q0 * ld), k,
-                                                    h->ws_key, h->ws_id);
-        RAG_HIP(hipGetLastError());
-        if (h->prof) {
-            RAG_HIP(hipEventRecord(e1, st));
-            h->ev_used.emplace_back(e0, e1);
-        }
-        merge_fn_t mf = pick_merge(KS, h->metric);
-        mf<<<(unsigned)NQ, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, (int)nb, k, D_dev + q0 * k,
-                                                   I_dev + q0 * k, (long long)id_base);
-        RAG_HIP(hipGetLastError());
-        q0 += NQ;
     }
     return RAG_OK;
 }
@@ -588,6 +635,8 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_id);
         (void)hipFree(h->ws_hq);
         (void)hipFree(h->ws_qn);
+        (void)hipFree(h->ws_fk);
+        (void)hipFree(h->ws_fi);
         (void)hipFree(h->xnorm);
         (void)hipFree(h->ws_D);
         (void)hipFree(h->ws_I);
@@ -687,7 +736,7 @@ int rag_flat_search_dev(rag_flat_t* h, int64_t nq, const float* q_dev, int k, fl
     RAG_REQUIRE_INIT();
     if (!h || nq < 0 || (nq > 0 && (!q_dev || !D_dev || !I_dev)))
         return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
-    if (k < 1 || k > RAG_MAX_K) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K);
+    if (k < 1 || k > RAG_MAX_K_TOTAL) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K_TOTAL);
     if (nq == 0) return RAG_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = flush_staged(h);
@@ -700,7 +749,7 @@ int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, 
     RAG_REQUIRE_INIT();
     if (!h || nq < 0 || (nq > 0 && (!q || !D || !I)))
         return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
-    if (k < 1 || k > RAG_MAX_K) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K);
+    if (k < 1 || k > RAG_MAX_K_TOTAL) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K_TOTAL);
     if (nq == 0) return RAG_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = flush_staged(h);

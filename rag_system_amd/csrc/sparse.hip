@@ -154,6 +154,12 @@ __global__ __launch_bounds__(256) void rank_kernel(const double* __restrict__ sc
     }
 }
 
+__global__ void gather_kernel(const double* __restrict__ score, int nq, const long long* __restrict__ qrow,
+                              double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) out[i] = score[qrow[i]];
+}
+
 }  // namespace
 
 struct rag_csc {
@@ -378,6 +384,27 @@ int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks
         rank_kernel<<<(unsigned)nb, 256, 0, st>>>(h->score, (long long)h->n_rows, nq, h->rk_rows, h->rk_out);
         RAG_HIP(hipGetLastError());
         RAG_HIP(hipMemcpyAsync(ranks + q0, h->rk_out, (size_t)nq * sizeof(long long), hipMemcpyDeviceToHost, st));
+        RAG_HIP(hipStreamSynchronize(st));
+    }
+    return RAG_OK;
+}
+
+int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_scores) {
+    RAG_REQUIRE_INIT();
+    if (!h || n_query < 0 || (n_query > 0 && (!rows || !out_scores))) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->have_scores) return fail(RAG_ERR_INVALID_ARG, "no score vector has been computed on this handle");
+    for (int i = 0; i < n_query; ++i)
+        if (rows[i] < 0 || rows[i] >= h->n_rows)
+            return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)rows[i], (long long)h->n_rows);
+    hipStream_t st = lib_stream();
+    for (int q0 = 0; q0 < n_query; q0 += RANK_MAXQ) {
+        const int nq = std::min(RANK_MAXQ, n_query - q0);
+        double* dout = reinterpret_cast<double*>(h->rk_out);  // same size: RANK_MAXQ * 8 bytes
+        RAG_HIP(hipMemcpyAsync(h->rk_rows, rows + q0, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
+        gather_kernel<<<(nq + 255) / 256, 256, 0, st>>>(h->score, nq, h->rk_rows, dout);
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipMemcpyAsync(out_scores + q0, dout, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, st));
         RAG_HIP(hipStreamSynchronize(st));
     }
     return RAG_OK;

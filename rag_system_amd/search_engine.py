@@ -1,0 +1,302 @@
+"""SearchEngine with the reference's strategies, scored by the MI355X engine.
+
+Mirrors rag_system/search_engine.py: detect_knee :37, SearchEngine :51 with
+search_with_strategy :76, search_faiss :138, search_bm25 :174, search_hybrid :195,
+search_multi_representation :272, search_rrf :320, reciprocal_rank_fusion :352,
+rerank_with_cross_encoder :362, mmr_selection :396.  Same arguments, same result dictionaries
+({doc_id, score, chunk, source} / {doc_id, score, text[, source]}, optional ce_score), same
+ordering rules (Python's stable descending sort => ties keep first-seen order).
+
+Where the reference loops over ALL documents in Python for the TF-IDF signal (dict over every
+doc :286, full sort :332-336), this engine keeps the score vector in HBM and asks it only for
+what the fusion can possibly use -- with identical results:
+  * a document outside the dense/BM25 candidate set A gets, in `rrf`, exactly 1/(60+rank) and,
+    in `multi`, exactly w_tfidf * score/max: both strictly ordered by its TF-IDF rank, so at most
+    the first top_k + |A| documents of the TF-IDF ranking can reach the final top_k;
+  * members of A need their own TF-IDF rank (rag_csc_ranks) or score (rag_csc_gather).
+Arithmetic on the (tiny) candidate set is done in Python floats in the reference's order.
+"""
+from typing import Any, Dict, List
+
+import numpy as np
+
+from . import candidates
+
+
+def detect_knee(scores: List[float]) -> float:
+    """Score right after the largest drop between consecutive (descending) scores."""
+    if len(scores) < 2:
+        return scores[0] if scores else 0.0
+    drops = [scores[i] - scores[i + 1] for i in range(len(scores) - 1)]
+    return scores[drops.index(max(drops)) + 1]
+
+
+def _rank_key(r):
+    return r.get("ce_score", r.get("score", 0.0))
+
+
+class SearchEngine:
+    def __init__(self, vector_storage, embedding_manager, cross_encoder=None, weight_dense=0.4, weight_bm25=0.3,
+                 weight_tfidf=0.3, verbose=False):
+        self.vector_storage = vector_storage
+        self.embedding_manager = embedding_manager
+        self.cross_encoder = cross_encoder
+        self.weight_dense = weight_dense
+        self.weight_bm25 = weight_bm25
+        self.weight_tfidf = weight_tfidf
+        self.verbose = verbose
+
+    def _debug(self, msg):
+        if self.verbose:
+            print("[DEBUG] " + msg)
+
+    # ------------------------------------------------------------------ dispatch
+
+    def search_with_strategy(self, query: str, strategy="faiss", top_k=10, retrieval_mode="chunk", threshold=0.0,
+                             use_knee_detection: bool = False, use_mmr: bool = False, mmr_lambda: float = 0.5,
+                             max_context_bytes: int = None) -> List[Dict[str, Any]]:
+        strategy = strategy.lower().strip()
+        retrieval_mode = retrieval_mode.lower().strip()
+        self._debug("search_with_strategy strategy=%s top_k=%s mode=%s threshold=%s"
+                    % (strategy, top_k, retrieval_mode, threshold))
+        if strategy == "faiss":
+            results = self.search_faiss(query, top_k, retrieval_mode)
+        elif strategy == "bm25":
+            results = self.search_bm25(query, top_k, retrieval_mode)
+        elif strategy in ("ibrido", "hybrid"):
+            results = self.search_hybrid(query, top_k, retrieval_mode)
+        elif strategy == "multi":
+            results = self.search_multi_representation(query, top_k, "document")
+        elif strategy == "rrf":
+            results = self.search_rrf(query, top_k, "document")
+        else:
+            raise ValueError(f"Unknown retrieval strategy: {strategy}")
+        results.sort(key=_rank_key, reverse=True)
+        if use_knee_detection and results:
+            cutoff = detect_knee([_rank_key(r) for r in results])
+            results = [r for r in results if _rank_key(r) > cutoff]
+        kept = [r for r in results if _rank_key(r) >= threshold]
+        if use_mmr and kept:
+            kept = self.mmr_selection(query, kept, self.embedding_manager, lambda_param=mmr_lambda, top_k=top_k,
+                                      max_context_bytes=max_context_bytes)
+        return kept
+
+    # ------------------------------------------------------------------ helpers
+
+    def _doc_text(self, doc_id):
+        info = self.vector_storage.documents.get(doc_id, {})
+        return " ".join(ch["chunk"] for ch in info.get("chunks", []))
+
+    @staticmethod
+    def _group_dense_by_doc(chunk_hits):
+        """doc_id -> {'score': max chunk score, 'chunks': chunk texts in hit order}; keys in first-hit order."""
+        groups = {}
+        for r in chunk_hits:
+            g = groups.get(r["doc_id"])
+            if g is None:
+                groups[r["doc_id"]] = {"score": r["score"], "chunks": [r["chunk"]]}
+            else:
+                g["score"] = max(g["score"], r["score"])
+                g["chunks"].append(r["chunk"])
+        return groups
+
+    def _dense_chunks(self, query, k):
+        q_vec = self.embedding_manager.embed_query(query)
+        hits = self.vector_storage.search(q_vec, top_k=k)
+        for r in hits:
+            r["score"] = float(r["score"])
+        return hits
+
+    # ------------------------------------------------------------------ single-signal strategies
+
+    def search_faiss(self, query: str, top_k=10, retrieval_mode="chunk") -> List[Dict[str, Any]]:
+        if "faiss" not in self.vector_storage.indices_present:
+            return []
+        if retrieval_mode == "document":
+            groups = self._group_dense_by_doc(self._dense_chunks(query, top_k * 3))
+            results = [{"doc_id": d, "score": g["score"], "text": " ".join(g["chunks"])} for d, g in groups.items()]
+        else:
+            results = self._dense_chunks(query, top_k)
+        if self.cross_encoder:
+            results = self.rerank_with_cross_encoder(query, results, normalize_ce=True)
+        results.sort(key=lambda x: x["score"], reverse=True)
+        return results[:top_k]
+
+    def search_bm25(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
+        if "bm25" not in self.vector_storage.indices_present:
+            return []
+        hits = self.vector_storage.search_bm25(query, top_k=top_k)
+        if retrieval_mode == "document":
+            # one entry per chunk hit, doc ids may repeat
+            docs = [{"doc_id": r["doc_id"], "score": r["score"], "text": self._doc_text(r["doc_id"])} for r in hits]
+            if self.cross_encoder:
+                docs = self.rerank_with_cross_encoder(query, docs, normalize_ce=False)
+            return docs
+        if self.cross_encoder:
+            hits = self.rerank_with_cross_encoder(query, hits, normalize_ce=True)
+        return hits
+
+    # ------------------------------------------------------------------ hybrid (dense + bm25, raw scores)
+
+    def search_hybrid(self, query: str, top_k=10, retrieval_mode="chunk") -> List[Dict[str, Any]]:
+        dense = []
+        if "faiss" in self.vector_storage.indices_present:
+            dense = self._dense_chunks(query, top_k * 3 if retrieval_mode == "document" else top_k)
+        sparse = []
+        if "bm25" in self.vector_storage.indices_present:
+            sparse = self.search_bm25(query, top_k=top_k, retrieval_mode=retrieval_mode)
+        fused = {}
+        if retrieval_mode == "document":
+            groups = self._group_dense_by_doc(dense)
+            for doc_id, g in groups.items():
+                fused[doc_id] = self.weight_dense * g["score"]
+            for r in sparse:
+                fused[r["doc_id"]] = fused.get(r["doc_id"], 0) + self.weight_bm25 * r["score"]
+            results = [{"doc_id": d, "score": s,
+                        "text": " ".join(groups[d]["chunks"]) if d in groups else self._doc_text(d),
+                        "source": "hybrid"} for d, s in fused.items()]
+        else:
+            best = {}   # doc_id -> (chunk text, score) of its best dense chunk (first wins ties)
+            for r in dense:
+                if r["doc_id"] not in best or r["score"] > best[r["doc_id"]][1]:
+                    best[r["doc_id"]] = (r["chunk"], r["score"])
+            for doc_id, (_txt, sc) in best.items():
+                fused[doc_id] = self.weight_dense * sc
+            for r in sparse:
+                if r["doc_id"] in best:   # bm25 only boosts documents the dense search found
+                    fused[r["doc_id"]] = fused.get(r["doc_id"], 0) + self.weight_bm25 * r["score"]
+            results = [{"doc_id": d, "score": s, "chunk": best[d][0] if d in best else "", "source": "hybrid"}
+                       for d, s in fused.items()]
+        results.sort(key=lambda x: x["score"], reverse=True)
+        results = results[:top_k]
+        if self.cross_encoder:
+            results = self.rerank_with_cross_encoder(query, results, normalize_ce=True)
+        return results
+
+    # ------------------------------------------------------------------ TF-IDF access
+
+    def _tfidf_for_candidates(self, query, cand_doc_ids, n_extra):
+        """Score the query against the HBM TF-IDF index once and return
+        (top_ids, top_scores): the first `n_extra` documents of the stable descending ranking,
+        (cand_rank, cand_score): TF-IDF rank / score of every candidate doc id that is indexed.
+        None if the store has no TF-IDF index."""
+        try:
+            scorer = self.vector_storage.get_tfidf_scorer()
+            doc_ids = self.vector_storage.tfidf_doc_ids
+        except Exception as e:
+            self._debug("get_tfidf_scorer failed: %s" % e)
+            scorer, doc_ids = None, []
+        if scorer is None:
+            return None
+        pos = getattr(self.vector_storage, "_tfidf_pos", None)
+        if pos is None or pos[0] is not doc_ids or len(pos[1]) != len(doc_ids):
+            pos = (doc_ids, {d: i for i, d in enumerate(doc_ids)})
+            self.vector_storage._tfidf_pos = pos
+        pos = pos[1]
+        top_idx, top_sc = scorer.top_k(query, min(n_extra, len(doc_ids)))
+        rows = [pos[d] for d in cand_doc_ids if d in pos]
+        ranks = scorer.ranks(rows) if rows else []
+        scores = scorer.gather(rows) if rows else []
+        cand = {doc_ids[r]: (int(rk), float(sc)) for r, rk, sc in zip(rows, ranks, scores)}
+        return [doc_ids[int(i)] for i in top_idx], [float(s) for s in top_sc], cand
+
+    # ------------------------------------------------------------------ multi (dense + bm25 + tfidf, max-normalised)
+
+    def search_multi_representation(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
+        dense = {d["doc_id"]: d["score"] for d in self.search_faiss(query, top_k=top_k * 3, retrieval_mode="document")}
+        bm25 = {d["doc_id"]: d["score"] for d in self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")}
+        cand_ids = list(dict.fromkeys(list(dense) + list(bm25)))
+        tf = self._tfidf_for_candidates(query, cand_ids, top_k + len(cand_ids))
+        tfidf = {}
+        tfidf_max = None
+        if tf is not None:
+            top_ids, top_sc, cand = tf
+            tfidf_max = top_sc[0] if top_sc else None          # max over ALL documents
+            for d in cand_ids:
+                if d in cand:
+                    tfidf[d] = cand[d][1]
+            for d, s in zip(top_ids, top_sc):
+                tfidf.setdefault(d, s)
+
+        def normalised(scores, mx=None):
+            if not scores:
+                return {}
+            mx = max(scores.values()) if mx is None else mx
+            return {k: v / mx for k, v in scores.items()} if mx > 0 else scores
+
+        dn, bn, tn = normalised(dense), normalised(bm25), normalised(tfidf, tfidf_max)
+        results = []
+        for doc_id in dict.fromkeys(list(dn) + list(bn) + list(tn)):
+            fused = (self.weight_dense * dn.get(doc_id, 0) + self.weight_bm25 * bn.get(doc_id, 0)
+                     + self.weight_tfidf * tn.get(doc_id, 0))
+            results.append({"doc_id": doc_id, "score": fused, "text": self._doc_text(doc_id)})
+        results.sort(key=lambda x: x["score"], reverse=True)
+        results = results[:top_k]
+        if self.cross_encoder:
+            results = self.rerank_with_cross_encoder(query, results, normalize_ce=True)
+        return results
+
+    # ------------------------------------------------------------------ rrf
+
+    def search_rrf(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
+        dense_ranking = self.search_faiss(query, top_k=top_k * 3, retrieval_mode="document")
+        bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+        fused = self.reciprocal_rank_fusion(dense_ranking, bm25_ranking, k=60)
+        tf = self._tfidf_for_candidates(query, list(fused), top_k + len(fused))
+        if tf is not None:
+            top_ids, _top_sc, cand = tf
+            for doc_id in fused:                       # candidates: their own rank among ALL documents
+                if doc_id in cand:
+                    fused[doc_id] = fused[doc_id] + 1.0 / (60 + cand[doc_id][0])
+            for rank, doc_id in enumerate(top_ids):    # the head of the TF-IDF ranking, in ranking order
+                if doc_id not in fused:
+                    fused[doc_id] = 0 + 1.0 / (60 + rank)
+        combined = [{"doc_id": d, "score": s, "text": self._doc_text(d)} for d, s in fused.items()]
+        combined.sort(key=lambda x: x["score"], reverse=True)
+        combined = combined[:top_k]
+        if self.cross_encoder:
+            combined = self.rerank_with_cross_encoder(query, combined, normalize_ce=True)
+        return combined
+
+    def reciprocal_rank_fusion(self, *rankings, k=60) -> Dict[str, float]:
+        """rrf[doc] += 1/(k+rank) over every entry of every ranking (each sorted by score, stable);
+        the accumulation runs in rag_rrf (csrc/cand.hip)."""
+        ordered = [[r["doc_id"] for r in sorted(ranking, key=lambda x: x["score"], reverse=True)]
+                   for ranking in rankings]
+        return candidates.reciprocal_rank_fusion(ordered, k=k)
+
+    # ------------------------------------------------------------------ cross-encoder hook (model is external)
+
+    def rerank_with_cross_encoder(self, query: str, results: List[Dict[str, Any]], normalize_ce: bool = True):
+        if not results:
+            return results
+        pairs = [(query, r.get("text", r.get("chunk", ""))) for r in results]
+        ce = np.array(self.cross_encoder.predict(pairs))
+        if normalize_ce:
+            lo, hi = (float(ce.min()), float(ce.max())) if ce.size else (0.0, 0.0)
+            if hi - lo > 1e-6:
+                vals = [(s - lo) / (hi - lo) for s in ce]
+            else:
+                vals = [0.5] * len(ce)
+        else:
+            vals = [float(s) for s in ce]
+        for r, v in zip(results, vals):
+            r["ce_score"] = v
+        results.sort(key=lambda x: x["ce_score"], reverse=True)
+        return results
+
+    # ------------------------------------------------------------------ MMR
+
+    def mmr_selection(self, query: str, results: List[Dict[str, Any]], embedding_manager, lambda_param: float = 0.5,
+                      top_k: int = None, max_context_bytes: int = None) -> List[Dict[str, Any]]:
+        """Greedy Maximal Marginal Relevance over the candidates' re-encoded texts; the cosine
+        matrix and the greedy loop run in rag_mmr (csrc/cand.hip)."""
+        if not results:
+            return results
+        top_k = top_k if top_k is not None else len(results)
+        texts = [r.get("chunk", r.get("text", "")) for r in results]
+        emb = np.array(embedding_manager.model.encode(texts), dtype="float32")
+        q = np.asarray(embedding_manager.embed_query(query), dtype="float32").reshape(-1)
+        byte_lens = [len(t.encode("utf-8")) for t in texts]
+        order = candidates.mmr_select(emb, q, byte_lens, lambda_param, top_k, max_context_bytes)
+        return [results[i] for i in order]

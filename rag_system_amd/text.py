@@ -1,0 +1,86 @@
+"""Host-side text helpers around the hot path (not part of it).
+
+word_tokenize: the reference tokenises BM25 chunks and queries with nltk.word_tokenize
+(vector_storage.py:162,177).  nltk (and its punkt data, fetched from the network at import in
+the reference) is an optional dependency here: when importable it is used, otherwise a regex
+tokenizer that splits words from punctuation the same way for plain prose.  Synthetic
+benchmarks use integer term ids, so tokenisation is outside every measured path.
+
+HashingEmbeddingManager: a deterministic, model-free stand-in for the reference's
+EmbeddingManager (embedding_manager.py:21) so that the store / search plumbing can run
+offline (BASELINE config #1 needs SentenceTransformer weights that cannot be fetched here).
+Producing embeddings is outside the hot path; real deployments pass the reference's own
+EmbeddingManager (any object with .model.encode, .embed_text, .embed_query works).
+"""
+import hashlib
+import re
+
+import numpy as np
+
+_TOKEN_RE = re.compile(r"\w+|[^\w\s]", re.UNICODE)
+
+
+def word_tokenize(text):
+    try:
+        from nltk.tokenize import word_tokenize as _nltk_tok
+        return _nltk_tok(text)
+    except Exception:  # nltk or its punkt data missing
+        return _TOKEN_RE.findall(text)
+
+
+class _HashingModel:
+    """encode(list[str]) -> (n, d) float32: signed hashed bag of words (not normalised)."""
+
+    def __init__(self, dim):
+        self.dim = dim
+
+    def encode(self, texts):
+        if isinstance(texts, str):
+            texts = [texts]
+        out = np.zeros((len(texts), self.dim), dtype=np.float32)
+        for i, t in enumerate(texts):
+            for w in re.findall(r"\w+", t.lower()):
+                h = int.from_bytes(hashlib.md5(w.encode("utf-8")).digest()[:8], "little")
+                out[i, h % self.dim] += 1.0 if (h >> 40) & 1 else -1.0
+                out[i, (h >> 20) % self.dim] += 0.5
+        return out
+
+
+class HashingEmbeddingManager:
+    """Same surface as the reference's EmbeddingManager: model.encode, embed_text, embed_query,
+    chunk_size / overlap / model_name."""
+
+    def __init__(self, dim=384, chunk_size=100, overlap=20, model_name="hashing-stub"):
+        self.model = _HashingModel(dim)
+        self.model_name = model_name
+        self.chunk_size = chunk_size
+        self.overlap = overlap
+        self.dim = dim
+
+    def set_chunk_params(self, chunk_size, overlap):
+        self.chunk_size = chunk_size
+        self.overlap = overlap
+
+    def _chunks(self, text):
+        words = text.split()
+        if len(words) < 50:
+            return [text]
+        step = max(1, self.chunk_size - self.overlap)
+        return [" ".join(words[i:i + self.chunk_size]) for i in range(0, len(words), step)
+                if i == 0 or i + self.overlap < len(words)]
+
+    def embed_text(self, text, doc_name=None):
+        chunk_texts = self._chunks(text)
+        emb = np.array(self.model.encode(chunk_texts), dtype="float32")
+        norms = np.linalg.norm(emb, axis=1, keepdims=True)
+        norms[norms == 0] = 1e-9
+        emb = emb / norms
+        chunks = [{"chunk": c, "source": doc_name} for c in chunk_texts] if doc_name is not None else chunk_texts
+        return chunks, emb
+
+    def embed_query(self, query):
+        vec = self.model.encode([query])[0].astype("float32")
+        norm = np.linalg.norm(vec)
+        if norm < 1e-9:
+            norm = 1.0
+        return vec / norm

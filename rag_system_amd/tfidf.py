@@ -70,3 +70,7 @@ class TfidfScorer:
         LAST scores()/top_k() call (search_engine.py:332-336 sorts all documents; RRF only
         needs the ranks of its candidates)."""
         return self._csc.ranks(doc_indices)
+
+    def gather(self, doc_indices):
+        """Scores of the given documents from the LAST scores()/top_k() call."""
+        return self._csc.gather(doc_indices)

@@ -302,3 +302,21 @@ def test_batched_results_identical_to_single_queries_ids(engine):
         D1, I1 = idx.search(Q[qi:qi + 1], 10)
         assert np.array_equal(I1[0], Ib[qi])
         assert np.allclose(D1[0], Db[qi], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_k_above_256_multi_pass(engine, metric):
+    """k > RAG_MAX_K is served in passes bounded by the previous pass' last entry."""
+    rng = np.random.default_rng(91 + metric)
+    X = _rand_unit(rng, 3000, 64)
+    X[1000:1300] = X[0:300]            # 300 exact duplicates: pass borders fall inside tie groups
+    idx = _index(64, metric)
+    idx.add(X)
+    for nq, k in [(1, 257), (3, 300), (2, 700), (6, 513), (1, 3000), (1, 4000)]:
+        Q = _rand_unit(rng, nq, 64)
+        D, I = idx.search(Q, k)
+        _, Ir, D64 = od.flat_search(X, Q, k, metric)
+        od.check_topk(D, I, D64, Ir, RTOL, ATOL, _scorer(X, Q, metric))
+        for qi in range(nq):            # no id may appear twice across passes
+            ids = I[qi][I[qi] >= 0]
+            assert len(set(ids.tolist())) == len(ids)
