@@ -19,7 +19,11 @@ W_DENSE, W_BM25, W_TFIDF = 0.4, 0.3, 0.3
 
 class RefState:
     def __init__(self, X, chunks, documents, bm25, bm25_chunks, tokenizer, vectorizer=None, tfidf=None,
-                 tfidf_doc_ids=()):
+                 tfidf_doc_ids=(), dense_fn=None):
+        # dense_fn(q (1,d), k) -> (D, I): lets a test substitute already-verified dense results
+        # (e.g. the GPU's, checked against od.flat_search separately) so that every later stage
+        # can be compared exactly instead of through near-tie tolerances.
+        self.dense_fn = dense_fn
         self.X = np.ascontiguousarray(X, dtype=np.float32)
         self.chunks = chunks              # [{doc_id, chunk, source}] aligned with X rows
         self.documents = documents        # doc_id -> {'chunks': [{'chunk','source'}]}
@@ -37,7 +41,11 @@ def _desc(items, key):
 def dense_chunks(st, qvec, k):
     if len(st.X) == 0:
         return []
-    D, I, _ = od.flat_search(st.X, np.asarray(qvec, np.float32).reshape(1, -1), k, od.METRIC_IP, accum64=True)
+    q = np.asarray(qvec, np.float32).reshape(1, -1)
+    if st.dense_fn is not None:
+        D, I = st.dense_fn(q, k)
+    else:
+        D, I, _ = od.flat_search(st.X, q, k, od.METRIC_IP, accum64=True)
     return [dict(doc_id=st.chunks[i]["doc_id"], score=float(s), chunk=st.chunks[i]["chunk"],
                  source=st.chunks[i]["source"]) for s, i in zip(D[0], I[0])]
 
