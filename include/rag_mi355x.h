@@ -120,7 +120,7 @@ int rag_flat_profiling(rag_flat_t* h, int enable);
  * (ntotal*d*sizeof(elem)). */
 int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double* bytes_per_launch);
 /* Tuning knobs for A/B runs in one process: "scan_blocks", "scan_nt",
- * "scan_rows", "mfma_min_nq". Unknown name -> RAG_ERR_INVALID_ARG. */
+ * "scan_rows", "mfma_min_nq", "mfma_shape", "mfma_bpc", "mfma_stages". Unknown name -> RAG_ERR_INVALID_ARG. */
 int rag_set_option(const char* name, int64_t value);
 
 /* ---- sparse scoring (BM25Okapi, TF-IDF cosine) ------------------------- */

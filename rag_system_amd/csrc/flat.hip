@@ -329,6 +329,7 @@ struct rag_flat {
     float* ws_fk = nullptr;  int64_t ws_fk_cap = 0;    // per-query floors for k > 256 passes
     int* ws_fi = nullptr;    int64_t ws_fi_cap = 0;
     float* ws_qn = nullptr;  int64_t ws_qn_cap = 0;    // ||q||^2 (L2, MFMA path)
+    float* zero16 = nullptr;                           // 64 B of zeros (MFMA tile padding source)
     float* xnorm = nullptr;  int64_t xnorm_cap = 0;    // ||x||^2 per row (L2, MFMA path), lazily filled
     int64_t norm_valid = 0;
     float* ws_hq = nullptr;  int64_t ws_hq_cap = 0;    // host-variant device copies
@@ -479,9 +480,9 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
 
     MfmaPlan plan;
     if (nq >= opt.mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, &plan)) {
-        rc = grow(h->ws_key, h->ws_key_cap, nq * plan.S * k);
+        rc = grow(h->ws_key, h->ws_key_cap, nq * plan.nlists * k);
         if (rc) return rc;
-        rc = grow(h->ws_id, h->ws_id_cap, nq * plan.S * k);
+        rc = grow(h->ws_id, h->ws_id_cap, nq * plan.nlists * k);
         if (rc) return rc;
         if (h->metric == RAG_METRIC_L2) {
             if (h->xnorm_cap < h->cap) {  // follow the arena
@@ -516,15 +517,19 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             }
             RAG_HIP(hipEventRecord(e0, st));
         }
+        if (!h->zero16) {
+            RAG_HIP(hipMalloc(&h->zero16, 64));
+            RAG_HIP(hipMemsetAsync(h->zero16, 0, 64, st));
+        }
         rc = mfma_launch(plan, h->x, (long long)n, ld, h->ws_q, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
-                         h->ws_qn, st);
+                         h->ws_qn, h->zero16, st);
         if (rc) return rc;
         if (h->prof) {
             RAG_HIP(hipEventRecord(e1, st));
             h->ev_used.emplace_back(e0, e1);
         }
         merge_fn_t mf = pick_merge(KS, h->metric);
-        mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.S, k, D_dev, I_dev, (long long)id_base, k, 0);
+        mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.nlists, k, D_dev, I_dev, (long long)id_base, k, 0);
         RAG_HIP(hipGetLastError());
         return RAG_OK;
     }
@@ -635,6 +640,7 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_id);
         (void)hipFree(h->ws_hq);
         (void)hipFree(h->ws_qn);
+        (void)hipFree(h->zero16);
         (void)hipFree(h->ws_fk);
         (void)hipFree(h->ws_fi);
         (void)hipFree(h->xnorm);

@@ -87,6 +87,9 @@ int rag_set_option(const char* name, int64_t value) {
     else if (!std::strcmp(name, "scan_nt")) o.scan_nt = value;
     else if (!std::strcmp(name, "scan_rows")) o.scan_rows = value;
     else if (!std::strcmp(name, "mfma_min_nq")) o.mfma_min_nq = value;
+    else if (!std::strcmp(name, "mfma_shape")) o.mfma_shape = value;
+    else if (!std::strcmp(name, "mfma_bpc")) o.mfma_bpc = value;
+    else if (!std::strcmp(name, "mfma_stages")) o.mfma_stages = value;
     else return rag::fail(RAG_ERR_INVALID_ARG, "unknown option '%s'", name);
     return RAG_OK;
 }

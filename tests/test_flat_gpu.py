@@ -320,3 +320,32 @@ def test_k_above_256_multi_pass(engine, metric):
         for qi in range(nq):            # no id may appear twice across passes
             ids = I[qi][I[qi] >= 0]
             assert len(set(ids.tolist())) == len(ids)
+
+
+def test_every_mfma_block_shape_and_ring_depth(engine):
+    """All built MFMA block shapes / K steps / LDS ring depths must give the same ids and
+    (bit-)identical scores: per-row summation order does not depend on the shape."""
+    from rag_system_amd import _lib
+    lib = _lib.engine()
+    rng = np.random.default_rng(123)
+    X = _rand_unit(rng, 9_001, 200)       # d = 200: K tail for both BK = 16 and BK = 32
+    X[4500] = X[17]
+    Q = _rand_unit(rng, 70, 200)
+    idx = _index(200)
+    idx.add(X)
+    _, Ir, D64 = od.flat_search(X, Q, 16, 0)
+    base = None
+    try:
+        for shape in range(1, 9):
+            for stages in (2, 3, 4):
+                _lib.check(lib.rag_set_option(b"mfma_shape", shape))
+                _lib.check(lib.rag_set_option(b"mfma_stages", stages))
+                D, I = idx.search(Q, 16)
+                od.check_topk(D, I, D64, Ir, RTOL, ATOL, _scorer(X, Q, 0))
+                if base is None:
+                    base = (D.copy(), I.copy())
+                assert np.array_equal(I, base[1]), (shape, stages)
+                assert np.array_equal(D, base[0]), (shape, stages)
+    finally:
+        lib.rag_set_option(b"mfma_shape", 0)
+        lib.rag_set_option(b"mfma_stages", 0)
