@@ -37,6 +37,10 @@ def lib():
         L.flat_search_ref.restype = None
         L.flat_search_synth_ref.argtypes = [u64, i64, i64, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp, vp]
         L.flat_search_synth_ref.restype = None
+        L.flat_search_synth_ref2.argtypes = [u64, i64, i64, C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+        L.flat_search_synth_ref2.restype = None
+        L.bf16_round_array.argtypes = [vp, i64, vp]
+        L.bf16_round_array.restype = None
         L.topk_merge_ref.argtypes = [C.c_int, C.c_int, i64, C.c_int, vp, vp, vp, vp]
         L.topk_merge_ref.restype = None
         L.flat_search_cpu_baseline.argtypes = [vp, i64, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]
@@ -77,13 +81,24 @@ def flat_search(X, Q, k, metric=METRIC_IP, accum64=True):
     return D, I, D64
 
 
-def flat_search_synth(seed, first_global_row, n, d, Q, k, metric=METRIC_IP):
+def bf16_round(a):
+    """float32 -> bfloat16 -> float32 (round-to-nearest-even): the storage rounding of a
+    RAG_DTYPE_BF16 index, applied to rows AND queries."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().bf16_round_array(_p(a), a.size, _p(out))
+    return out
+
+
+def flat_search_synth(seed, first_global_row, n, d, Q, k, metric=METRIC_IP, bf16=False):
+    """bf16=True: rows are rounded to bfloat16 after generation; Q must already be rounded."""
     Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, d)
     nq = Q.shape[0]
     D = np.empty((nq, k), dtype=np.float32)
     I = np.empty((nq, k), dtype=np.int64)
     D64 = np.empty((nq, k), dtype=np.float64)
-    lib().flat_search_synth_ref(seed, first_global_row, n, d, _p(Q), nq, k, metric, _p(D), _p(I), _p(D64))
+    lib().flat_search_synth_ref2(seed, first_global_row, n, d, _p(Q), nq, k, metric, 1 if bf16 else 0,
+                                 _p(D), _p(I), _p(D64))
     return D, I, D64
 
 

@@ -71,6 +71,22 @@ void synth_row(uint64_t seed, int64_t global_row, int d, float* out) {
     }
 }
 
+/* float -> bfloat16 -> float, round-to-nearest-even on the upper 16 bits (NaN stays quiet):
+ * the storage rounding of a RAG_DTYPE_BF16 index and of the queries searched against it.
+ * Not in the reference (faiss IndexFlat is fp32); BASELINE.json config 3 names bf16 rows. */
+static inline float bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) u = (u | 0x00400000u) & 0xFFFF0000u;
+    else u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void bf16_round_array(const float* in, int64_t n, float* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = bf16_rne(in[i]);
+}
+
 void synth_rows(uint64_t seed, int64_t first_global_row, int64_t n, int d, float* out) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) synth_row(seed, first_global_row + i, d, out + i * (int64_t)d);
@@ -171,8 +187,18 @@ void flat_search_ref(const float* X, int64_t n, int d, const float* Q, int64_t n
 /* Same search over the synthetic corpus rows [first_global_row, first_global_row+n),
  * generated on the fly (nothing stored), parallel over row blocks.  Ids are local
  * (0..n-1).  Used for full-size checks (10M x 384) without 15 GB of host memory. */
+void flat_search_synth_ref2(uint64_t seed, int64_t first_global_row, int64_t n, int d, const float* Q,
+                            int64_t nq, int k, int metric, int bf16_rows, float* D, int64_t* I, double* D64);
+
 void flat_search_synth_ref(uint64_t seed, int64_t first_global_row, int64_t n, int d, const float* Q,
                            int64_t nq, int k, int metric, float* D, int64_t* I, double* D64) {
+    flat_search_synth_ref2(seed, first_global_row, n, d, Q, nq, k, metric, 0, D, I, D64);
+}
+
+/* bf16_rows != 0: every generated row is rounded to bfloat16 before scoring (the caller
+ * rounds Q the same way). */
+void flat_search_synth_ref2(uint64_t seed, int64_t first_global_row, int64_t n, int d, const float* Q,
+                            int64_t nq, int k, int metric, int bf16_rows, float* D, int64_t* I, double* D64) {
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
@@ -189,6 +215,8 @@ void flat_search_synth_ref(uint64_t seed, int64_t first_global_row, int64_t n, i
 #pragma omp for schedule(static)
         for (int64_t r = 0; r < n; ++r) {
             synth_row(seed, first_global_row + r, d, row);
+            if (bf16_rows)
+                for (int c = 0; c < d; ++c) row[c] = bf16_rne(row[c]);
             for (int64_t qi = 0; qi < nq; ++qi) {
                 double s = score_row(row, Q + qi * (int64_t)d, d, metric, 1);
                 topk_push(&lists[(int64_t)tid * nq + qi], metric == METRIC_IP ? s : -s, r);

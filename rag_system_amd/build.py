@@ -50,7 +50,7 @@ def _compile(src, force):
     return obj
 
 
-def build_lib(force=False, jobs=4):
+def build_lib(force=False, jobs=8):
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=jobs) as ex:

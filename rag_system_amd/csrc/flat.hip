@@ -3,7 +3,11 @@
 // Replaces faiss' IndexFlat.search (vector_storage.py:196) and .add (:105,:152).
 //
 // HBM layout: one arena per index, row-major, row stride `ld` elements (d rounded up to a
-// multiple of 4 floats so every row starts 16-byte aligned; pad columns are zero).
+// multiple of 4 floats / 8 bfloat16 so every row starts 16-byte aligned; pad columns are zero).
+// RAG_DTYPE_BF16: rows are rounded to bfloat16 (round-to-nearest-even) when added and the
+// QUERY is rounded the same way at search time, in every kernel; products of two bfloat16
+// are exact in fp32 and accumulation is fp32, so the scores are those of the rounded
+// operands to fp32 accuracy whatever the batch size.
 //
 // Small query batches (nq <= 4 per pass): flat_scan_kernel -- a bandwidth-bound fused GEMV.
 //   * every wave streams tiles of R consecutive rows with 16-byte coalesced loads
@@ -26,6 +30,18 @@ namespace {
 using namespace rag;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// float -> bfloat16 bits, round-to-nearest-even (NaN stays a quiet NaN); oracle/flat_ref.c
+// bf16_rne() is the same function.
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_WAVES = SCAN_THREADS / 64;
@@ -51,7 +67,19 @@ __device__ __forceinline__ float dot4_acc(f32x4 x, f32x4 q, float acc) {
     return acc;
 }
 
-template <int R, int NQ, int KS, int METRIC, bool NT>
+// 8 bfloat16 (one 16-byte chunk) against 8 fp32 query values, in element order.
+template <int METRIC>
+__device__ __forceinline__ float dot8_acc(u32x4 x, f32x4 qa, f32x4 qb, float acc) {
+    f32x4 lo, hi;
+    lo.x = bf16_lo(x.x); lo.y = bf16_hi(x.x); lo.z = bf16_lo(x.y); lo.w = bf16_hi(x.y);
+    hi.x = bf16_lo(x.z); hi.y = bf16_hi(x.z); hi.z = bf16_lo(x.w); hi.w = bf16_hi(x.w);
+    acc = dot4_acc<METRIC>(lo, qa, acc);
+    return dot4_acc<METRIC>(hi, qb, acc);
+}
+
+// d4 = 16-byte chunks per stored row (ld/4 for fp32 rows, ld/8 for bfloat16 rows).  Q4: NQ
+// query rows of ld fp32 values (already rounded to bfloat16 values for a bfloat16 index).
+template <int R, int NQ, int KS, int METRIC, bool NT, bool BF>
 __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
     const f32x4* __restrict__ X4, long long n, int d4, const f32x4* __restrict__ Q4, int k,
     float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ floor_key,
@@ -60,7 +88,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
     f32x4* q_lds = reinterpret_cast<f32x4*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
-    for (int i = tid; i < NQ * d4; i += SCAN_THREADS) q_lds[i] = Q4[i];
+    if (!BF) {
+        for (int i = tid; i < NQ * d4; i += SCAN_THREADS) q_lds[i] = Q4[i];
+    } else {
+        // a 16-byte chunk of 8 bfloat16 meets two float4 of the query: keep the even float4s
+        // of a query row in [0, d4) and the odd ones in [d4, 2*d4) so both reads are lane-linear
+        for (int i = tid; i < NQ * 2 * d4; i += SCAN_THREADS) {
+            const int q = i / (2 * d4), j = i - q * 2 * d4;
+            q_lds[q * 2 * d4 + (j & 1) * d4 + (j >> 1)] = Q4[i];
+        }
+    }
     __syncthreads();
 
     using TK = WaveTopK<float, int, KS>;
@@ -111,9 +148,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const f32x4 qv = q_lds[q * d4 + idx];
+                    if (!BF) {
+                        const f32x4 qv = q_lds[q * d4 + idx];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[q * R + r] = dot4_acc<METRIC>(xv[r], qv, acc[q * R + r]);
+                        for (int r = 0; r < R; ++r) acc[q * R + r] = dot4_acc<METRIC>(xv[r], qv, acc[q * R + r]);
+                    } else {
+                        const f32x4 qa = q_lds[q * 2 * d4 + idx];
+                        const f32x4 qb = q_lds[q * 2 * d4 + d4 + idx];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            acc[q * R + r] = dot8_acc<METRIC>(__builtin_bit_cast(u32x4, xv[r]), qa, qb, acc[q * R + r]);
+                    }
                 }
             }
         }
@@ -133,7 +178,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
     }
 
     // ---- merge the block's four wave lists through LDS, wave 0 writes one list per query
-    const int qbytes = ((NQ * d4 * 16) + 15) & ~15;
+    const int qbytes = NQ * d4 * 16 * (BF ? 2 : 1);
     float* mk = reinterpret_cast<float*>(smem_raw + qbytes);
     int* mi = reinterpret_cast<int*>(mk + (SCAN_WAVES - 1) * NQ * KS * 64);
     if (wid > 0) {
@@ -263,14 +308,43 @@ __global__ void fill_pad_kernel(float* D, long long* I, long long total, float d
     }
 }
 
-// Queries (nq x d) -> zero-padded (nq x ld).
-__global__ void pad_queries_kernel(const float* __restrict__ q, float* __restrict__ qpad, long long nq, int d,
-                                   int ld) {
+// Queries (nq x d) -> zero-padded (nq x ld).  bfloat16 index (qb != nullptr): the fp32 copy
+// holds the ROUNDED values and qb the same values as bfloat16 (MFMA operand).
+__global__ void pad_queries_kernel(const float* __restrict__ q, float* __restrict__ qpad,
+                                   unsigned short* __restrict__ qb, long long nq, int d, int ld) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq * ld) {
         const long long r = i / ld;
         const int c = (int)(i - r * ld);
-        qpad[i] = c < d ? q[r * d + c] : 0.0f;
+        float v = c < d ? q[r * d + c] : 0.0f;
+        if (qb) {
+            const unsigned short b = bf16_rne(v);
+            qb[i] = b;
+            v = __uint_as_float((unsigned int)b << 16);
+        }
+        qpad[i] = v;
+    }
+}
+
+// fp32 rows (n x d, dense) -> bfloat16 arena rows (n x ld, pad columns zero).
+__global__ void rows_to_bf16_kernel(const float* __restrict__ src, int d, unsigned short* __restrict__ dst, int ld,
+                                    long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * ld) {
+        const long long r = i / ld;
+        const int c = (int)(i - r * ld);
+        dst[i] = c < d ? bf16_rne(src[r * d + c]) : (unsigned short)0;
+    }
+}
+
+// bfloat16 arena rows -> fp32 rows (n x d, dense); exact widening.
+__global__ void rows_from_bf16_kernel(const unsigned short* __restrict__ src, int ld, float* __restrict__ dst, int d,
+                                      long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * d) {
+        const long long r = i / d;
+        const int c = (int)(i - r * d);
+        dst[i] = __uint_as_float((unsigned int)src[r * ld + c] << 16);
     }
 }
 
@@ -291,7 +365,8 @@ __device__ __forceinline__ int synth_int(unsigned long long row_key, int col) {
 
 // One wave per row; bit-identical to oracle/flat_ref.c:synth_row (integer sum of squares is
 // exact, sqrt and the division are IEEE double, one rounding to float).
-__global__ __launch_bounds__(256) void synth_rows_kernel(float* __restrict__ X, int ld, int d, long long n,
+template <bool BF>
+__global__ __launch_bounds__(256) void synth_rows_kernel(void* __restrict__ Xv, int ld, int d, long long n,
                                                          unsigned long long seed, long long first_global) {
     const int lane = threadIdx.x & 63;
     const long long W = (long long)gridDim.x * 4;
@@ -305,9 +380,11 @@ __global__ __launch_bounds__(256) void synth_rows_kernel(float* __restrict__ X, 
         }
         for (int dist = 32; dist >= 1; dist >>= 1) ss += __shfl_xor(ss, dist);
         const double nrm = sqrt((double)ss);
-        float* row = X + r * ld;
-        for (int c = lane; c < ld; c += 64)
-            row[c] = c < d ? (float)((double)synth_int(key, c) / nrm) : 0.0f;
+        for (int c = lane; c < ld; c += 64) {
+            const float v = c < d ? (float)((double)synth_int(key, c) / nrm) : 0.0f;
+            if (BF) reinterpret_cast<unsigned short*>(Xv)[r * ld + c] = bf16_rne(v);
+            else reinterpret_cast<float*>(Xv)[r * ld + c] = v;
+        }
     }
 }
 
@@ -317,10 +394,13 @@ __global__ __launch_bounds__(256) void synth_rows_kernel(float* __restrict__ X, 
 
 struct rag_flat {
     int d = 0, ld = 0, metric = 0, dtype = 0;
+    int esz = 4;             // bytes per stored element (4 fp32, 2 bfloat16)
     int64_t ntotal = 0;      // rows visible to search (device rows + staged rows)
     int64_t ndev = 0;        // rows resident in HBM
     int64_t cap = 0;         // arena capacity in rows
-    float* x = nullptr;      // HBM arena, cap * ld floats
+    char* x = nullptr;       // HBM arena, cap * ld elements of esz bytes
+    float* ws_cvt = nullptr; int64_t ws_cvt_cap = 0;   // fp32 staging for bfloat16 conversion
+    unsigned short* ws_qb = nullptr; int64_t ws_qb_cap = 0;  // bfloat16 queries (MFMA operand)
     std::vector<float> staged;  // host rows not yet flushed (d floats each)
     // search workspace (HBM)
     float* ws_q = nullptr;   int64_t ws_q_cap = 0;     // padded queries
@@ -347,27 +427,42 @@ constexpr int64_t STAGE_FLUSH_FLOATS = 16 << 20;  // 64 MiB of staged rows
 int ensure_capacity(rag_flat* h, int64_t rows) {
     if (rows <= h->cap) return RAG_OK;
     int64_t want = std::max<int64_t>(rows, std::max<int64_t>(h->cap * 2, 1024));
-    float* nx = nullptr;
-    hipError_t e = hipMalloc(&nx, (size_t)want * h->ld * sizeof(float));
+    char* nx = nullptr;
+    const size_t rb = (size_t)h->ld * h->esz;
+    hipError_t e = hipMalloc(&nx, (size_t)want * rb);
     if (e != hipSuccess && want > rows) {
         (void)hipGetLastError();
         want = rows;
-        e = hipMalloc(&nx, (size_t)want * h->ld * sizeof(float));
+        e = hipMalloc(&nx, (size_t)want * rb);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        return fail(RAG_ERR_OOM, "hipMalloc of %lld rows x %d floats failed: %s", (long long)want, h->ld,
+        return fail(RAG_ERR_OOM, "hipMalloc of %lld rows x %zu bytes failed: %s", (long long)want, rb,
                     hipGetErrorString(e));
     }
     hipStream_t st = lib_stream();
     if (h->ld != h->d)  // pad columns must read as zero
-        RAG_HIP(hipMemsetAsync(nx, 0, (size_t)want * h->ld * sizeof(float), st));
+        RAG_HIP(hipMemsetAsync(nx, 0, (size_t)want * rb, st));
     if (h->ndev > 0)
-        RAG_HIP(hipMemcpyAsync(nx, h->x, (size_t)h->ndev * h->ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RAG_HIP(hipMemcpyAsync(nx, h->x, (size_t)h->ndev * rb, hipMemcpyDeviceToDevice, st));
     RAG_HIP(hipStreamSynchronize(st));
     if (h->x) RAG_HIP(hipFree(h->x));
     h->x = nx;
     h->cap = want;
+    return RAG_OK;
+}
+
+template <typename T>
+int grow(T*& p, int64_t& cap, int64_t need);
+
+constexpr int64_t CVT_CHUNK_FLOATS = 32 << 20;  // 128 MiB of fp32 per conversion chunk
+
+// fp32 device rows (n x d dense) -> bfloat16 arena rows starting at row `first`.
+int convert_rows_dev(rag_flat* h, const float* src_dev, int64_t first, int64_t n, hipStream_t st) {
+    const long long total = (long long)n * h->ld;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(h->x) + (size_t)first * h->ld;
+    rows_to_bf16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src_dev, h->d, dst, h->ld, (long long)n);
+    RAG_HIP(hipGetLastError());
     return RAG_OK;
 }
 
@@ -376,7 +471,22 @@ int upload_rows(rag_flat* h, const float* src, int64_t n) {
     if (n <= 0) return RAG_OK;
     int rc = ensure_capacity(h, h->ndev + n);
     if (rc) return rc;
-    float* dst = h->x + (size_t)h->ndev * h->ld;
+    if (h->dtype == RAG_DTYPE_BF16) {
+        const int64_t rows_per = std::max<int64_t>(1, CVT_CHUNK_FLOATS / h->d);
+        hipStream_t st = lib_stream();
+        rc = grow(h->ws_cvt, h->ws_cvt_cap, std::min(n, rows_per) * h->d);
+        if (rc) return rc;
+        for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
+            const int64_t m = std::min(rows_per, n - r0);
+            RAG_HIP(hipMemcpyAsync(h->ws_cvt, src + r0 * h->d, (size_t)m * h->d * sizeof(float), hipMemcpyHostToDevice, st));
+            rc = convert_rows_dev(h, h->ws_cvt, h->ndev + r0, m, st);
+            if (rc) return rc;
+            RAG_HIP(hipStreamSynchronize(st));
+        }
+        h->ndev += n;
+        return RAG_OK;
+    }
+    float* dst = reinterpret_cast<float*>(h->x) + (size_t)h->ndev * h->ld;
     if (h->ld == h->d)
         RAG_HIP(hipMemcpy(dst, src, (size_t)n * h->d * sizeof(float), hipMemcpyHostToDevice));
     else
@@ -410,33 +520,39 @@ int grow(T*& p, int64_t& cap, int64_t need) {
 
 struct ScanCfg {
     int R, NQ, KS, metric;
-    bool nt;
+    bool nt, bf;
 };
 
 typedef void (*scan_fn_t)(const f32x4*, long long, int, const f32x4*, int, float*, int*, const float*, const int*);
 
-template <int R, int NQ, int KS>
-scan_fn_t pick_scan2(int metric, bool nt) {
+template <int R, int NQ, int KS, bool BF>
+scan_fn_t pick_scan3(int metric, bool nt) {
     if (metric == RAG_METRIC_IP)
-        return nt ? flat_scan_kernel<R, NQ, KS, RAG_METRIC_IP, true> : flat_scan_kernel<R, NQ, KS, RAG_METRIC_IP, false>;
-    return nt ? flat_scan_kernel<R, NQ, KS, RAG_METRIC_L2, true> : flat_scan_kernel<R, NQ, KS, RAG_METRIC_L2, false>;
+        return nt ? flat_scan_kernel<R, NQ, KS, RAG_METRIC_IP, true, BF>
+                  : flat_scan_kernel<R, NQ, KS, RAG_METRIC_IP, false, BF>;
+    return nt ? flat_scan_kernel<R, NQ, KS, RAG_METRIC_L2, true, BF>
+              : flat_scan_kernel<R, NQ, KS, RAG_METRIC_L2, false, BF>;
+}
+template <int R, int NQ, int KS>
+scan_fn_t pick_scan2(int metric, bool nt, bool bf) {
+    return bf ? pick_scan3<R, NQ, KS, true>(metric, nt) : pick_scan3<R, NQ, KS, false>(metric, nt);
 }
 template <int R, int NQ>
-scan_fn_t pick_scan1(int KS, int metric, bool nt) {
+scan_fn_t pick_scan1(int KS, int metric, bool nt, bool bf) {
     switch (KS) {
-        case 1: return pick_scan2<R, NQ, 1>(metric, nt);
-        case 2: return pick_scan2<R, NQ, 2>(metric, nt);
-        default: return pick_scan2<R, NQ, 4>(metric, nt);
+        case 1: return pick_scan2<R, NQ, 1>(metric, nt, bf);
+        case 2: return pick_scan2<R, NQ, 2>(metric, nt, bf);
+        default: return pick_scan2<R, NQ, 4>(metric, nt, bf);
     }
 }
 scan_fn_t pick_scan(const ScanCfg& c) {
     if (c.NQ == 1) {
-        if (c.R == 2) return pick_scan1<2, 1>(c.KS, c.metric, c.nt);
-        if (c.R == 8) return pick_scan1<8, 1>(c.KS, c.metric, c.nt);
-        return pick_scan1<4, 1>(c.KS, c.metric, c.nt);
+        if (c.R == 2) return pick_scan1<2, 1>(c.KS, c.metric, c.nt, c.bf);
+        if (c.R == 8) return pick_scan1<8, 1>(c.KS, c.metric, c.nt, c.bf);
+        return pick_scan1<4, 1>(c.KS, c.metric, c.nt, c.bf);
     }
-    if (c.NQ == 2) return pick_scan1<4, 2>(c.KS, c.metric, c.nt);
-    return pick_scan1<4, 4>(c.KS, c.metric, c.nt);
+    if (c.NQ == 2) return pick_scan1<4, 2>(c.KS, c.metric, c.nt, c.bf);
+    return pick_scan1<4, 4>(c.KS, c.metric, c.nt, c.bf);
 }
 
 typedef void (*merge_fn_t)(const float*, const int*, int, int, float*, long long*, long long, int, int);
@@ -466,20 +582,27 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     }
     if (n > (int64_t)INT_MAX - 8)
         return fail(RAG_ERR_UNSUPPORTED, "more than 2^31-9 rows in one shard (%lld)", (long long)n);
-    const int ld = h->ld, d4 = ld / 4;
+    const bool bf = h->dtype == RAG_DTYPE_BF16;
+    const int ld = h->ld, q4 = ld / 4;      // float4 per fp32 query row
+    const int dch = ld * h->esz / 16;       // 16-byte chunks per stored row
     const Options& opt = options();
     const int KS = ks_for(k > RAG_MAX_K ? RAG_MAX_K : k);
 
     int rc = grow(h->ws_q, h->ws_q_cap, nq * ld);
     if (rc) return rc;
+    if (bf) {
+        rc = grow(h->ws_qb, h->ws_qb_cap, nq * ld);
+        if (rc) return rc;
+    }
     {
         const long long total = nq * ld;
-        pad_queries_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(q_dev, h->ws_q, nq, h->d, ld);
+        pad_queries_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(q_dev, h->ws_q, bf ? h->ws_qb : nullptr, nq,
+                                                                           h->d, ld);
         RAG_HIP(hipGetLastError());
     }
 
     MfmaPlan plan;
-    if (nq >= opt.mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, &plan)) {
+    if (nq >= opt.mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan)) {
         rc = grow(h->ws_key, h->ws_key_cap, nq * plan.nlists * k);
         if (rc) return rc;
         rc = grow(h->ws_id, h->ws_id_cap, nq * plan.nlists * k);
@@ -496,13 +619,13 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                 h->xnorm_cap = h->cap;
             }
             if (h->norm_valid < n) {
-                rc = mfma_row_norms(h->x, ld, h->norm_valid, n - h->norm_valid, h->xnorm, st);
+                rc = mfma_row_norms(h->x, ld, bf, h->norm_valid, n - h->norm_valid, h->xnorm, st);
                 if (rc) return rc;
                 h->norm_valid = n;
             }
             rc = grow(h->ws_qn, h->ws_qn_cap, nq);
             if (rc) return rc;
-            rc = mfma_row_norms(h->ws_q, ld, 0, nq, h->ws_qn, st);
+            rc = mfma_row_norms(h->ws_q, ld, false, 0, nq, h->ws_qn, st);
             if (rc) return rc;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -521,8 +644,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             RAG_HIP(hipMalloc(&h->zero16, 64));
             RAG_HIP(hipMemsetAsync(h->zero16, 0, 64, st));
         }
-        rc = mfma_launch(plan, h->x, (long long)n, ld, h->ws_q, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
-                         h->ws_qn, h->zero16, st);
+        // the kernel moves 16-byte chunks: both operands are addressed in 4-byte words
+        rc = mfma_launch(plan, reinterpret_cast<const float*>(h->x), (long long)n, ld * h->esz / 4,
+                         bf ? reinterpret_cast<const float*>(h->ws_qb) : h->ws_q, (int)nq, k, h->metric, h->ws_key,
+                         h->ws_id, h->xnorm, h->ws_qn, h->zero16, st);
         if (rc) return rc;
         if (h->prof) {
             RAG_HIP(hipEventRecord(e1, st));
@@ -565,11 +690,11 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             if (rc) return rc;
             rc = grow(h->ws_id, h->ws_id_cap, (int64_t)NQ * nb * kp);
             if (rc) return rc;
-            const size_t qbytes = (size_t)(((int64_t)NQ * d4 * 16 + 15) & ~15LL);
+            const size_t qbytes = (size_t)NQ * q4 * 16;
             const size_t smem = qbytes + (size_t)(SCAN_WAVES - 1) * NQ * KSp * 64 * 8;
             if (smem > 160 * 1024)
                 return fail(RAG_ERR_UNSUPPORTED, "d=%d too large for the LDS-resident query (%zu B)", h->d, smem);
-            ScanCfg cfg{R, NQ, KSp, h->metric, opt.scan_nt != 0};
+            ScanCfg cfg{R, NQ, KSp, h->metric, opt.scan_nt != 0, bf};
             scan_fn_t fn = pick_scan(cfg);
             if (smem > 48 * 1024)
                 RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
@@ -586,7 +711,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                 }
                 RAG_HIP(hipEventRecord(e0, st));
             }
-            fn<<<(unsigned)nb, SCAN_THREADS, smem, st>>>(reinterpret_cast<const f32x4*>(h->x), (long long)n, d4,
+            fn<<<(unsigned)nb, SCAN_THREADS, smem, st>>>(reinterpret_cast<const f32x4*>(h->x), (long long)n, dch,
                                                         reinterpret_cast<const f32x4*>(h->ws_q + q0 * ld), kp,
                                                         h->ws_key, h->ws_id, fl_k ? fl_k + q0 : nullptr,
                                                         fl_i ? fl_i + q0 : nullptr);
@@ -618,11 +743,12 @@ int rag_flat_create(int d, int metric, int storage_dtype, rag_flat_t** out) {
     if (d <= 0 || d > 8192) return fail(RAG_ERR_INVALID_ARG, "d=%d out of range [1,8192]", d);
     if (metric != RAG_METRIC_IP && metric != RAG_METRIC_L2)
         return fail(RAG_ERR_INVALID_ARG, "metric %d is neither IP(0) nor L2(1)", metric);
-    if (storage_dtype != RAG_DTYPE_F32)
-        return fail(RAG_ERR_UNSUPPORTED, "storage dtype %d not built yet (fp32 only)", storage_dtype);
+    if (storage_dtype != RAG_DTYPE_F32 && storage_dtype != RAG_DTYPE_BF16)
+        return fail(RAG_ERR_INVALID_ARG, "storage dtype %d is neither fp32(0) nor bf16(1)", storage_dtype);
     rag_flat* h = new rag_flat();
     h->d = d;
-    h->ld = (d + 3) & ~3;
+    h->esz = storage_dtype == RAG_DTYPE_BF16 ? 2 : 4;
+    h->ld = storage_dtype == RAG_DTYPE_BF16 ? ((d + 7) & ~7) : ((d + 3) & ~3);
     h->metric = metric;
     h->dtype = storage_dtype;
     *out = h;
@@ -636,6 +762,8 @@ void rag_flat_free(rag_flat_t* h) {
         if (lib_stream()) (void)hipStreamSynchronize(lib_stream());
         (void)hipFree(h->x);
         (void)hipFree(h->ws_q);
+        (void)hipFree(h->ws_qb);
+        (void)hipFree(h->ws_cvt);
         (void)hipFree(h->ws_key);
         (void)hipFree(h->ws_id);
         (void)hipFree(h->ws_hq);
@@ -691,8 +819,11 @@ int rag_flat_add_dev(rag_flat_t* h, int64_t n, const float* x_dev, void* stream)
     rc = ensure_capacity(h, h->ndev + n);
     if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : lib_stream();
-    float* dst = h->x + (size_t)h->ndev * h->ld;
-    if (h->ld == h->d)
+    float* dst = reinterpret_cast<float*>(h->x) + (size_t)h->ndev * h->ld;
+    if (h->dtype == RAG_DTYPE_BF16) {
+        rc = convert_rows_dev(h, x_dev, h->ndev, n, st);
+        if (rc) return rc;
+    } else if (h->ld == h->d)
         RAG_HIP(hipMemcpyAsync(dst, x_dev, (size_t)n * h->d * sizeof(float), hipMemcpyDeviceToDevice, st));
     else
         RAG_HIP(hipMemcpy2DAsync(dst, (size_t)h->ld * sizeof(float), x_dev, (size_t)h->d * sizeof(float),
@@ -714,8 +845,13 @@ int rag_flat_add_synthetic(rag_flat_t* h, int64_t n, uint64_t seed, int64_t firs
     if (rc) return rc;
     hipStream_t st = lib_stream();
     const int64_t nb = std::min<int64_t>((n + 3) / 4, (int64_t)num_cus() * 8);
-    synth_rows_kernel<<<(unsigned)nb, 256, 0, st>>>(h->x + (size_t)h->ndev * h->ld, h->ld, h->d, (long long)n,
-                                                   (unsigned long long)seed, (long long)first_global_row);
+    void* dst = h->x + (size_t)h->ndev * h->ld * h->esz;
+    if (h->dtype == RAG_DTYPE_BF16)
+        synth_rows_kernel<true><<<(unsigned)nb, 256, 0, st>>>(dst, h->ld, h->d, (long long)n, (unsigned long long)seed,
+                                                             (long long)first_global_row);
+    else
+        synth_rows_kernel<false><<<(unsigned)nb, 256, 0, st>>>(dst, h->ld, h->d, (long long)n, (unsigned long long)seed,
+                                                              (long long)first_global_row);
     RAG_HIP(hipGetLastError());
     RAG_HIP(hipStreamSynchronize(st));
     h->ndev += n;
@@ -792,7 +928,24 @@ int rag_flat_copy_to_host(rag_flat_t* h, int64_t first, int64_t n, float* out) {
     int rc = flush_staged(h);
     if (rc) return rc;
     RAG_HIP(hipStreamSynchronize(lib_stream()));
-    const float* src = h->x + (size_t)first * h->ld;
+    if (h->dtype == RAG_DTYPE_BF16) {  // exact widening of the stored (rounded) values
+        hipStream_t st = lib_stream();
+        const int64_t rows_per = std::max<int64_t>(1, CVT_CHUNK_FLOATS / h->d);
+        rc = grow(h->ws_cvt, h->ws_cvt_cap, std::min(n, rows_per) * h->d);
+        if (rc) return rc;
+        for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
+            const int64_t m = std::min(rows_per, n - r0);
+            const long long total = (long long)m * h->d;
+            rows_from_bf16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+                reinterpret_cast<const unsigned short*>(h->x) + (size_t)(first + r0) * h->ld, h->ld, h->ws_cvt, h->d,
+                (long long)m);
+            RAG_HIP(hipGetLastError());
+            RAG_HIP(hipMemcpyAsync(out + r0 * h->d, h->ws_cvt, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
+            RAG_HIP(hipStreamSynchronize(st));
+        }
+        return RAG_OK;
+    }
+    const float* src = reinterpret_cast<const float*>(h->x) + (size_t)first * h->ld;
     if (h->ld == h->d)
         RAG_HIP(hipMemcpy(out, src, (size_t)n * h->d * sizeof(float), hipMemcpyDeviceToHost));
     else
@@ -844,7 +997,7 @@ int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double
     h->ev_used.clear();
     if (n_launches) *n_launches = cnt;
     if (total_ms) *total_ms = sum;
-    if (bytes_per_launch) *bytes_per_launch = (double)h->ndev * h->d * sizeof(float);
+    if (bytes_per_launch) *bytes_per_launch = (double)h->ndev * h->d * h->esz;
     return RAG_OK;
 }
 

@@ -9,15 +9,18 @@ struct MfmaPlan {
     int WM, WN;     // waves per block along rows / queries (block covers 32*WN queries)
     int MT;         // 32-row accumulator tiles per wave (block covers 32*MT*WM rows)
     int NS;         // LDS-DMA ring stages
+    int KS;         // 64-entry register slots per top-k list (1: k <= 64, 2: k <= 128)
+    bool bf16;      // rows and queries are bfloat16 (two per 4-byte word)
     int S;          // row splits
     int col_tiles;  // query tiles
     int nlists;     // candidate lists written per query = S * WM
 };
 
-// false if the MFMA path does not serve this shape (k > 64): caller falls back to the scan kernel.
-bool mfma_plan(long long n, long long nq, int k, MfmaPlan* p);
-// out[first + i] = ||X[first + i]||^2 for i in [0, n)
-int mfma_row_norms(const float* X, int ld, long long first, long long n, float* out, hipStream_t st);
+// false if the MFMA path does not serve this shape (k > 128): caller falls back to the scan kernel.
+bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p);
+// out[first + i] = ||X[first + i]||^2 for i in [0, n); ld in elements (fp32 or bfloat16 rows)
+int mfma_row_norms(const void* X, int ld, bool bf16, long long first, long long n, float* out, hipStream_t st);
+// X / Qp are addressed in 4-byte words (ld = words per row; bfloat16: two elements per word).
 // Qp: queries zero-padded to (>= nq) x ld.  cand_*: [nq][nlists][k].  xnorm/qnorm only for L2.
 // zero16: >= 16 bytes of zeros in HBM (source of out-of-range K columns / queries).
 int mfma_launch(const MfmaPlan& p, const float* X, long long n, int ld, const float* Qp, int nq, int k, int metric,

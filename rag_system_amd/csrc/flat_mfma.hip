@@ -1,397 +1,56 @@
-// flat_mfma.hip -- query batches: exact-f32 MFMA GEMM tile fused with per-query top-k.
-//
-// The one place the search path is a real dense contraction (BASELINE.json north_star):
-// S[row, q] = sum_k X[row, k] * Q[q, k] for nq >= 5 queries, followed by top-k over rows.
-// Uses v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit a k-ordered fmaf chain, no
-// TF32/xf32 on gfx950), peak 157 TFLOP/s = the bound for nq >~ 40 (ridge ~20 flop/B).
-//
-// Tiling (one workgroup = WM x WN waves, always 4 or 8 so every SIMD of the CU gets the same
-// number of waves):
-//   block tile   BM = 32*MT*WM rows  x  BN = 32*WN queries,  K step BK = 16 floats
-//   wave (wm,wn) rows [32*MT*wm, +32*MT) x queries [32*wn, +32): MT accumulator tiles of 32x32.
-//                A wave owns its (row slice, query column) pairs outright: its top-k lists and
-//                thresholds are wave-private, no cross-wave synchronisation in the epilogue.
-//   operands     A = X tile (row = lane&31, k = lane>>5), B = Q^T tile (query = lane&31);
-//                C layout: column (lane&31) = query, 16 registers = rows
-//                (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> a lane compares its 16 rows against
-//                ITS query's threshold with plain v_cmp, no shuffles.
-//   LDS          NS-stage ring of X and Q tiles, 64-byte rows, 16-byte chunks XOR-swizzled by
-//                (row>>2)&3 (conflict-free ds_read_b128 over any 16 rows distinct mod 16);
-//                per-(wave, query) sorted k-lists; 32-float scratch per wave for the column
-//                transposition on a threshold hit.
-//   pipeline     direct-to-LDS loads (global_load_lds_dwordx4, no staging registers): stage
-//                e+NS-1 is issued while stage e is multiplied; LDS stays linear per wave
-//                instruction, the swizzle is applied to the per-lane SOURCE address and to the
-//                fragment reads; counted s_waitcnt vmcnt(N) + one raw s_barrier per K step;
-//                the K loop runs on across row tiles so there is no bubble between tiles.
-//   grid         row_splits x query_tiles persistent blocks; block b works on row tiles
-//                s, s+S, ...; blocks that share a row split (different query tiles) get
-//                consecutive ids with equal b%8 so they share an XCD's L2 (speed only).
-// Epilogue per row tile: ballot the lanes with a score above their query's current k-th
-// key (rare once warm); for each such query dump its column to scratch, offer the 32 rows
-// to the LDS-resident list through the wave-cooperative WaveTopK insert, refresh the
-// threshold.  The score matrix is never written to HBM.  Every (block, wm) pair writes one
-// k-list per query; flat_merge_kernel merges the S*WM lists.
+// flat_mfma.hip -- host side of the MFMA batch path: block-shape plan, row norms, dispatch.
+// The kernel lives in flat_mfma_kernel.h and is instantiated per element type in
+// flat_mfma_f32.hip / flat_mfma_bf16.hip.
 #include "common.h"
 #include "flat_mfma.h"
-#include "topk.h"
+#include "flat_mfma_kernel.h"
 
 namespace {
 
 using namespace rag;
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// K step: BK floats per row per stage (16 or 32).  LDS rows are BK floats (64 / 128 bytes) made
-// of CH = BK/4 16-byte chunks; the chunk position is XOR-swizzled with f(row) = (row>>2)&3 (CH=4)
-// or (row>>1)&7 (CH=8), which makes ds_read_b128 over 16 rows distinct mod 16 conflict-free.
-// BK=32 fetches whole 128-byte lines per row and halves the barriers per flop.
-template <int BK>
-__device__ __forceinline__ int swz(int row) {
-    return BK == 16 ? (row >> 2) & 3 : (row >> 1) & 7;
-}
-
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    // 64 lanes x 16 B -> LDS [lds_wave_base + 16*lane]; asynchronous, counted by vmcnt
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt [3:0]+[15:14], expcnt [6:4], lgkmcnt [11:8]).
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
-}
-
-template <int WM, int WN, int MT, int BK, int NS, int METRIC>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma_kernel(
-    const float* __restrict__ X, long long n, int ld, const float* __restrict__ Qp, int nq, int k, int S,
-    int col_tiles, float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
-    const float* __restrict__ qnorm, const float* __restrict__ zero16) {
-    constexpr int NWV = WM * WN;
-    constexpr int T = 64 * NWV;
-    constexpr int BMW = 32 * MT;          // rows per wave
-    constexpr int BM = BMW * WM;
-    constexpr int BN = 32 * WN;
-    constexpr int CH = BK / 4;            // 16-byte chunks per tile row
-    constexpr int LDS_LD = BK;            // tile row stride in floats
-    constexpr int XI = BM * CH / 64;      // wave-instructions (1 KiB each) per X tile
-    constexpr int QI = BN * CH / 64;      // ... per Q tile
-    constexpr int XQ = XI / NWV;          // per wave
-    constexpr int QQ = (QI + NWV - 1) / NWV;
-    constexpr int LPS = XQ + QQ;          // LDS-DMA instructions per wave per stage
-    static_assert(XI % NWV == 0, "X tile must split evenly over the waves");
-    static_assert(NS >= 2 && (NS - 2) * LPS < 64, "stage ring too deep for vmcnt");
-
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    float* Xs = reinterpret_cast<float*>(smem_raw);                 // [NS][BM][LDS_LD]
-    float* Qs = Xs + NS * BM * LDS_LD;                              // [NS][BN][LDS_LD]
-    float* dummy = Qs + NS * BN * LDS_LD;                           // [256] sink of filler loads
-    float* lkey = dummy + 256;                                      // [NWV][32][k]
-    int* lid = reinterpret_cast<int*>(lkey + NWV * 32 * k);         // [NWV][32][k]
-    float* scratch = reinterpret_cast<float*>(lid + NWV * 32 * k);  // [NWV][32]
-    float* xn_s = scratch + NWV * 32;                               // [BM] row norms (L2 only)
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int wn = wid % WN, wm = wid / WN;
-
-    int s, c;
-    {
-        const int b = blockIdx.x;
-        if ((S & 7) == 0) {
-            const int xcd = b & 7, t_ = b >> 3;
-            c = t_ % col_tiles;
-            s = (t_ / col_tiles) * 8 + xcd;
-        } else {
-            c = b % col_tiles;
-            s = b / col_tiles;
-        }
-    }
-    const int q0 = c * BN;
-    const long long ntiles = (n + BM - 1) / BM;
-    const long long my_tiles = s < ntiles ? (ntiles - s + S - 1) / S : 0;
-    const int nk = (ld + BK - 1) / BK;
-    const long long total = my_tiles * nk;
-
-    // lists start as pads
-    for (int i = tid; i < NWV * 32 * k; i += T) {
-        lkey[i] = Lowest<float>::v();
-        lid[i] = IdPad<int>::v();
-    }
-    float thr = Lowest<float>::v();  // current k-th key of this lane's query (within this wave's rows)
-    float qn = 0.f;
-    if (METRIC == RAG_METRIC_L2) {
-        const int qi = q0 + 32 * wn + li;
-        qn = qi < nq ? qnorm[qi] : 0.f;
-    }
-
-    // Direct-to-LDS tile loads.  LDS slot s (16 B) of a tile holds row s/CH, physical chunk s%CH =
-    // logical chunk (s%CH) ^ swz(row).  A wave instruction fills 64 consecutive slots;
-    // out-of-range K columns / queries read zeros.  Steps past the end and waves without a Q
-    // share still issue (zero-source / sink) loads so that every wave has the same number of
-    // outstanding operations in every iteration, which is what the counted waits rely on.
-    //
-    // Everything that does not change from one K step to the next is hoisted: per lane and
-    // per instruction the element offset of its (row, chunk) and the chunk's column, refreshed
-    // once per row tile; per K step an address is one 64-bit add.
-    const bool ktail = (ld % BK) != 0;        // only then can a chunk fall beyond the row
-    long long xoff[XQ];                       // element offset of this lane's chunk at k0 = 0 (current prefetch tile)
-    int xcol[XQ];                             // 4 * logical chunk
-    long long qoff[QQ];                       // same for the query tile; < 0: no query behind this slot
-    int qcol[QQ];
-#pragma unroll
-    for (int it = 0; it < XQ; ++it) {
-        const int slot = (it * NWV + wid) * 64 + lane;
-        xcol[it] = 4 * ((slot % CH) ^ swz<BK>(slot / CH));
-    }
-#pragma unroll
-    for (int it = 0; it < QQ; ++it) {
-        const int slot = (it * NWV + wid) * 64 + lane;
-        const int r = slot / CH;
-        qcol[it] = 4 * ((slot % CH) ^ swz<BK>(r));
-        qoff[it] = (it * NWV + wid < QI && q0 + r < nq) ? (long long)(q0 + r) * ld + qcol[it] : -1;
-    }
-    long long pf_tiles_left = my_tiles;       // prefetch cursor: tiles not yet fully issued
-    long long pf_row0 = (long long)s * BM;
-    int pf_ks = 0;
-    auto set_tile_offsets = [&]() {
-#pragma unroll
-        for (int it = 0; it < XQ; ++it) {
-            const int slot = (it * NWV + wid) * 64 + lane;
-            long long row = pf_row0 + slot / CH;
-            row = row < n ? row : n - 1;
-            xoff[it] = row * ld + xcol[it];
-        }
-    };
-    set_tile_offsets();
-    auto issue_loads = [&](int buf) {
-        float* xs = Xs + buf * BM * LDS_LD;
-        float* qs = Qs + buf * BN * LDS_LD;
-        if (pf_tiles_left > 0) {
-            const int k0 = pf_ks * BK;
-#pragma unroll
-            for (int it = 0; it < XQ; ++it) {
-                const float* gp = X + xoff[it] + k0;
-                if (ktail && k0 + xcol[it] >= ld) gp = zero16;
-                glds16(gp, xs + (it * NWV + wid) * 256);
-            }
-#pragma unroll
-            for (int it = 0; it < QQ; ++it) {
-                if (it * NWV + wid < QI) {  // wave-uniform
-                    const float* gp = qoff[it] >= 0 ? Qp + qoff[it] + k0 : zero16;
-                    if (ktail && k0 + qcol[it] >= ld) gp = zero16;
-                    glds16(gp, qs + (it * NWV + wid) * 256);
-                } else {
-                    glds16(zero16, dummy);
-                }
-            }
-            if (++pf_ks == nk) {
-                pf_ks = 0;
-                pf_row0 += (long long)S * BM;
-                if (--pf_tiles_left > 0) set_tile_offsets();
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < LPS; ++it) glds16(zero16, dummy);
-        }
-    };
-
-    f32x16 acc[MT];
-    using TK = WaveTopK<float, int, 1>;
-
-    // NS-stage ring: stages e .. e+NS-2 are in flight at the top of iteration e.
-    __syncthreads();  // list initialisation visible before any epilogue
-#pragma unroll
-    for (int st = 0; st < NS - 1; ++st) issue_loads(st);
-
-    int cur = 0;
-    int ks = 0;                                // K step within the current row tile
-    long long row0 = (long long)s * BM;        // first row of the current row tile
-    for (long long e = 0; e < total; ++e) {
-        // this wave's share of stage e has landed; after the barrier everyone's has, and
-        // everyone is done reading the buffer of stage e-1, which the next issue overwrites
-        wait_vmcnt<(NS - 2) * LPS>();
-        __builtin_amdgcn_s_barrier();
-        {
-            int nxt = cur + NS - 1;
-            nxt = nxt >= NS ? nxt - NS : nxt;
-            issue_loads(nxt);
-        }
-        if (ks == 0) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        }
-        {
-            const float* xs = Xs + cur * BM * LDS_LD + wm * BMW * LDS_LD;
-            const float* qs = Qs + cur * BN * LDS_LD;
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                const int sw = swz<BK>(li);  // = swz(row): every tile starts at a multiple of 32 rows
-                const int pc = ((kk * 2 + lh) ^ sw) * 4;
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(qs + (32 * wn + li) * LDS_LD + pc);
-                f32x4 a[MT];
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    a[t] = *reinterpret_cast<const f32x4*>(xs + (32 * t + li) * LDS_LD + pc);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][cc], bq[cc], acc[t], 0, 0, 0);
-            }
-        }
-        if (ks == nk - 1) {
-            // ---- epilogue of one row tile: threshold filter + list update
-            const bool partial = row0 + BM > n;
-            if (METRIC == RAG_METRIC_L2) {
-                __syncthreads();
-                for (int i = tid; i < BM; i += T) {
-                    const long long row = row0 + i;
-                    xn_s[i] = row < n ? xnorm[row] : 0.f;
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int tile_off = wm * BMW + 32 * t;
-                const long long rowbase = row0 + tile_off;
-                float key[16];
-                bool any = false;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = acc[t][r];
-                    if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn_s[tile_off + ro]) - qn;
-                    key[r] = v;
-                    bool ok = v > thr;
-                    if (partial) ok = ok && (rowbase + ro < n);
-                    any = any || ok;
-                }
-                const unsigned long long m = __ballot(any);
-                unsigned qm = (unsigned)(m | (m >> 32));
-                while (qm) {
-                    const int j = __ffs(qm) - 1;
-                    qm &= qm - 1;
-                    float* sc = scratch + wid * 32;
-                    if (li == j) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[(r & 3) + 8 * (r >> 2) + 4 * lh] = key[r];
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const float cs = sc[li];
-                    const long long crow = rowbase + li;
-                    TK tk;
-                    const int lo = (32 * wid + j) * k;
-                    tk.key[0] = lane < k ? lkey[lo + lane] : Lowest<float>::v();
-                    tk.id[0] = lane < k ? lid[lo + lane] : IdPad<int>::v();
-                    float thr_k;
-                    int thr_i;
-                    tk.kth(k, thr_k, thr_i);
-                    wave_offer<float, int, 1>(tk, k, thr_k, thr_i, cs, (int)crow, lane < 32 && crow < n, lane);
-                    if (lane < k) {
-                        lkey[lo + lane] = tk.key[0];
-                        lid[lo + lane] = tk.id[0];
-                    }
-                    if (li == j) thr = thr_k;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-        }
-        cur = cur + 1 == NS ? 0 : cur + 1;
-        if (++ks == nk) {
-            ks = 0;
-            row0 += (long long)S * BM;
-        }
-    }
-    wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
-
-    // ---- write the lists of every real query: cand[q][s*WM + wm][k]
-    __syncthreads();
-    for (int i = tid; i < NWV * 32 * k; i += T) {
-        const int w = i / (32 * k), rem = i - w * 32 * k;
-        const int j = rem / k, p = rem - j * k;
-        const int qi = q0 + 32 * (w % WN) + j;
-        if (qi < nq) {
-            const long long o = ((long long)qi * (S * WM) + (long long)s * WM + (w / WN)) * k + p;
-            cand_key[o] = lkey[i];
-            cand_id[o] = lid[i];
-        }
-    }
-}
-
 // ||x||^2 per row (fp32, same fmaf order on every call) for the L2 decomposition.
-__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ X, int ld, long long first,
+template <bool BF>
+__global__ __launch_bounds__(256) void row_norms_kernel(const void* __restrict__ Xv, int ld, long long first,
                                                         long long n, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const long long W = (long long)gridDim.x * 4;
     for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += W) {
-        const float* row = X + (first + r) * ld;
         float ss = 0.f;
-        for (int cidx = lane; cidx < ld; cidx += 64) ss = fmaf(row[cidx], row[cidx], ss);
+        for (int cidx = lane; cidx < ld; cidx += 64) {
+            float v;
+            if (BF) v = __uint_as_float((unsigned int)reinterpret_cast<const unsigned short*>(Xv)[(first + r) * ld + cidx] << 16);
+            else v = reinterpret_cast<const float*>(Xv)[(first + r) * ld + cidx];
+            ss = fmaf(v, v, ss);
+        }
         for (int dist = 32; dist >= 1; dist >>= 1) ss += __shfl_xor(ss, dist);
         if (lane == 0) out[first + r] = ss;
     }
 }
 
-size_t smem_need(int WM, int WN, int MT, int BK, int NS, int k) {
-    const size_t BM = 32 * (size_t)MT * WM, BN = 32 * (size_t)WN, NWV = (size_t)WM * WN;
-    return NS * (BM + BN) * BK * 4 + 1024 + NWV * 32 * (size_t)k * 8 + NWV * 128 + BM * 4;
-}
-
-template <int WM, int WN, int MT, int BK, int NS>
-int launch(const MfmaPlan& p, const float* X, long long n, int ld, const float* Qp, int nq, int k, int metric,
-           float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, const float* zero16,
-           hipStream_t st) {
-    const size_t smem = smem_need(WM, WN, MT, BK, NS, k);
-    auto fn = metric == RAG_METRIC_IP ? flat_mfma_kernel<WM, WN, MT, BK, NS, RAG_METRIC_IP>
-                                      : flat_mfma_kernel<WM, WN, MT, BK, NS, RAG_METRIC_L2>;
-    if (smem > 48 * 1024)
-        RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)smem));
-    fn<<<(unsigned)(p.S * p.col_tiles), 64 * WM * WN, smem, st>>>(X, n, ld, Qp, nq, k, p.S, p.col_tiles, cand_key,
-                                                                 cand_id, xnorm, qnorm, zero16);
-    RAG_HIP(hipGetLastError());
-    return RAG_OK;
-}
-
-// The block shapes that are built.  bpc = blocks per CU the grid is sized for.
-struct Shape {
-    int WM, WN, MT, BK, bpc;
-};
-constexpr Shape SHAPES[] = {
-    {4, 1, 2, 16, 2},  // 1: <= 32 queries, 256 rows
-    {2, 2, 4, 16, 2},  // 2: <= 64 queries, 256 rows
-    {1, 4, 8, 16, 2},  // 3: <= 128 queries, 256 rows, two decoupled 4-wave blocks per CU
-    {1, 8, 8, 16, 1},  // 4: 256 queries, 256 rows, one 8-wave block per CU
-    {4, 1, 2, 32, 1},  // 5: <= 32 queries, whole 128-byte lines
-    {2, 2, 4, 32, 1},  // 6: <= 64 queries
-    {1, 4, 8, 32, 1},  // 7: <= 128 queries
-    {1, 8, 8, 32, 1},  // 8: 256 queries
-};
-constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
-
 }  // namespace
 
 namespace rag {
 
-bool mfma_plan(long long n, long long nq, int k, MfmaPlan* p) {
-    if (k > 64 || nq < 1 || n < 1) return false;
-    int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));
+using mfma::SHAPES;
+using mfma::NSHAPES;
+using mfma::Shape;
+
+bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
+    if (k > 128 || nq < 1 || n < 1) return false;
+    const int KS = k > 64 ? 2 : 1;
+    int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 4));
     const long long force = options().mfma_shape;
     if (force >= 1 && force <= NSHAPES) shape = (int)force - 1;
+    if (KS == 2 && SHAPES[shape].WM * SHAPES[shape].WN > 4) shape = SHAPES[shape].BK == 32 ? 6 : 2;
     int NS = 3;
-    if (options().mfma_stages >= 2 && options().mfma_stages <= 4) NS = (int)options().mfma_stages;
+    if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
     int bpc = SHAPES[shape].bpc;
     if (options().mfma_bpc > 0) bpc = (int)options().mfma_bpc;
     // fit LDS: shrink the ring first, then fall back to a 4-wave shape (fewer per-wave lists)
     for (;;) {
         const Shape& sh = SHAPES[shape];
-        if (smem_need(sh.WM, sh.WN, sh.MT, sh.BK, NS, k) * bpc <= 160 * 1024) break;
+        if (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.BK, NS, k) * bpc <= 160 * 1024) break;
         if (NS > 2) { --NS; continue; }
         if (bpc > 1) { --bpc; NS = 3; continue; }
         if (shape != 2) { shape = 2; bpc = 1; NS = 3; continue; }
@@ -403,6 +62,8 @@ bool mfma_plan(long long n, long long nq, int k, MfmaPlan* p) {
     p->WN = sh.WN;
     p->MT = sh.MT;
     p->NS = NS;
+    p->KS = KS;
+    p->bf16 = bf16;
     const int BN = 32 * sh.WN, BM = 32 * sh.MT * sh.WM;
     p->col_tiles = (int)((nq + BN - 1) / BN);
     const long long ntiles = (n + BM - 1) / BM;
@@ -415,11 +76,12 @@ bool mfma_plan(long long n, long long nq, int k, MfmaPlan* p) {
     return true;
 }
 
-int mfma_row_norms(const float* X, int ld, long long first, long long n, float* out, hipStream_t st) {
+int mfma_row_norms(const void* X, int ld, bool bf16, long long first, long long n, float* out, hipStream_t st) {
     if (n <= 0) return RAG_OK;
     long long nb = (n + 3) / 4;
     if (nb > (long long)num_cus() * 8) nb = (long long)num_cus() * 8;
-    row_norms_kernel<<<(unsigned)nb, 256, 0, st>>>(X, ld, first, n, out);
+    if (bf16) row_norms_kernel<true><<<(unsigned)nb, 256, 0, st>>>(X, ld, first, n, out);
+    else row_norms_kernel<false><<<(unsigned)nb, 256, 0, st>>>(X, ld, first, n, out);
     RAG_HIP(hipGetLastError());
     return RAG_OK;
 }
@@ -427,22 +89,8 @@ int mfma_row_norms(const float* X, int ld, long long first, long long n, float* 
 int mfma_launch(const MfmaPlan& p, const float* X, long long n, int ld, const float* Qp, int nq, int k, int metric,
                 float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, const float* zero16,
                 hipStream_t st) {
-#define RAG_MFMA_ARGS p, X, n, ld, Qp, nq, k, metric, cand_key, cand_id, xnorm, qnorm, zero16, st
-#define RAG_MFMA_NS(WM, WN, MT, BK)                                              \
-    (p.NS >= 4 ? launch<WM, WN, MT, BK, 4>(RAG_MFMA_ARGS)                          \
-               : (p.NS == 3 ? launch<WM, WN, MT, BK, 3>(RAG_MFMA_ARGS) : launch<WM, WN, MT, BK, 2>(RAG_MFMA_ARGS)))
-    switch (p.shape) {
-        case 0: return RAG_MFMA_NS(4, 1, 2, 16);
-        case 1: return RAG_MFMA_NS(2, 2, 4, 16);
-        case 2: return RAG_MFMA_NS(1, 4, 8, 16);
-        case 3: return RAG_MFMA_NS(1, 8, 8, 16);
-        case 4: return RAG_MFMA_NS(4, 1, 2, 32);
-        case 5: return RAG_MFMA_NS(2, 2, 4, 32);
-        case 6: return RAG_MFMA_NS(1, 4, 8, 32);
-        default: return RAG_MFMA_NS(1, 8, 8, 32);
-    }
-#undef RAG_MFMA_NS
-#undef RAG_MFMA_ARGS
+    const mfma::Args a{X, n, ld, Qp, nq, k, metric, cand_key, cand_id, xnorm, qnorm, zero16, st};
+    return p.bf16 ? mfma::dispatch_bf16(p, a) : mfma::dispatch_f32(p, a);
 }
 
 }  // namespace rag

@@ -25,10 +25,13 @@ METRIC_L2 = 1
 class _HipFlatBackend:
     """rag_flat_t handle (include/rag_mi355x.h)."""
 
-    def __init__(self, d, metric):
+    def __init__(self, d, metric, storage="f32"):
+        if storage not in ("f32", "bf16"):
+            raise ValueError("storage must be 'f32' or 'bf16', got %r" % (storage,))
         self._lib = _lib.engine()
         h = C.c_void_p()
-        _lib.check(self._lib.rag_flat_create(int(d), int(metric), _lib.DTYPE_F32, C.byref(h)), self._lib)
+        dtype = _lib.DTYPE_BF16 if storage == "bf16" else _lib.DTYPE_F32
+        _lib.check(self._lib.rag_flat_create(int(d), int(metric), dtype, C.byref(h)), self._lib)
         self._h = h
         self.d = int(d)
 
@@ -95,15 +98,22 @@ def set_backend_factory(factory):
 
 
 class IndexFlat:
-    """faiss.IndexFlat: exact search over raw float32 vectors."""
+    """faiss.IndexFlat: exact search over raw float32 vectors.
 
-    def __init__(self, d, metric=METRIC_INNER_PRODUCT):
+    storage="bf16" (no counterpart in the reference; BASELINE.json config 3): rows are kept
+    as bfloat16 (round-to-nearest-even) and queries are rounded the same way at search time;
+    scores are the fp32-accumulated products of the rounded operands.  reconstruct_n /
+    write_index then return the rounded rows."""
+
+    def __init__(self, d, metric=METRIC_INNER_PRODUCT, storage="f32"):
         if int(d) <= 0:
             raise ValueError("d must be positive")
         self.d = int(d)
         self.metric_type = int(metric)
         self.is_trained = True
-        self._b = _backend_factory(self.d, self.metric_type)
+        self.storage = storage
+        self._b = (_backend_factory(self.d, self.metric_type) if storage == "f32"
+                   else _backend_factory(self.d, self.metric_type, storage))
 
     @property
     def ntotal(self):

@@ -1,0 +1,185 @@
+"""GPU parity tests of the bfloat16-row index (RAG_DTYPE_BF16, BASELINE.json config 3).
+
+Definition under test (include/rag_mi355x.h): rows AND queries are rounded to bfloat16
+(round-to-nearest-even), products are exact in fp32, accumulation is fp32.  So:
+  * against the float64 oracle evaluated on the ROUNDED operands the bar is the fp32 one
+    (1e-5 relative, ids identical except near-ties);
+  * against the un-rounded fp32 scores the stated bound is
+        |s_bf16 - s_fp32| <= 2^-8 (1 + 2^-10) * sum_i |x_i q_i|  <=  ~3.91e-3 * |x| |q|
+    (each operand carries a relative rounding error <= 2^-9), and recall@k against the exact
+    fp32 result is reported.
+The reference has no bf16 path and no fixture for it: PARITY UNPINNED beyond the rounding
+itself, which oracle/flat_ref.c:bf16_rne shares bit-for-bit with torch's float32->bfloat16
+cast (checked in tests/test_oracle_cpu.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import dense as od
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+ATOL = 2e-6
+BF16_BOUND = 2.0 ** -8 * (1 + 2.0 ** -10)
+
+
+def _index(d, metric=0):
+    from rag_system_amd import faiss_compat as faiss
+    return faiss.IndexFlat(d, metric, storage="bf16")
+
+
+def _rand_unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+    return x
+
+
+def _scorer(Xr, Qr, metric):
+    X64, Q64 = Xr.astype(np.float64), Qr.astype(np.float64)
+
+    def f(qi, ids):
+        rows = X64[ids]
+        return rows @ Q64[qi] if metric == 0 else ((rows - Q64[qi]) ** 2).sum(axis=1)
+    return f
+
+
+def _check(idx, X, Q, k, metric, atol=ATOL):
+    Xr, Qr = od.bf16_round(X), od.bf16_round(Q)
+    D, I = idx.search(Q, k)                      # un-rounded queries in: the engine rounds them
+    _, Ir, D64 = od.flat_search(Xr, Qr, k, metric)
+    od.check_topk(D, I, D64, Ir, RTOL, atol, _scorer(Xr, Qr, metric))
+    return D, I
+
+
+def test_storage_rounds_to_nearest_even_and_reconstructs(engine):
+    rng = np.random.default_rng(5)
+    for n, d in [(1000, 384), (513, 37), (64, 768), (3, 8)]:
+        X = (rng.standard_normal((n, d)) * rng.choice([1e-3, 1.0, 50.0], size=(n, 1))).astype(np.float32)
+        X[0, :4] = [1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, -0.0, 1e-40]   # ties-to-even both ways, -0, denormal
+        idx = _index(d)
+        idx.add(X[: n // 2])
+        for r in X[n // 2:]:
+            idx.add(r.reshape(1, -1))                                    # staged row-at-a-time path
+        assert idx.ntotal == n
+        assert idx.reconstruct_n(0, n).tobytes() == od.bf16_round(X).tobytes()
+    # device generator: same rows as the oracle's, rounded
+    idx = _index(384)
+    idx._b.add_synthetic(1000, 1234, 77)
+    assert idx.reconstruct_n(0, 1000).tobytes() == od.bf16_round(od.synth_rows(1234, 77, 1000, 384)).tobytes()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d", [(1, 384), (7, 768), (1000, 384), (4099, 768), (3001, 37), (257, 8),
+                                 (50_003, 384), (300, 2050)])
+def test_scan_matches_oracle_on_rounded_operands(engine, n, d, metric):
+    rng = np.random.default_rng(n * 13 + d)
+    X = _rand_unit(rng, n, d)
+    if n > 100:
+        X[n // 2] = X[3]
+        X[n - 1] = X[3]
+    idx = _index(d, metric)
+    idx.add(X)
+    for nq, k in [(1, 10), (2, 30), (3, 1), (4, 100), (1, 256), (2, 300)]:
+        Q = _rand_unit(rng, nq, d)
+        Q[0] = X[min(3, n - 1)]
+        _check(idx, X, Q, k, metric)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d", [(1, 384), (300, 768), (4099, 768), (3001, 37), (20_011, 384), (1000, 24)])
+def test_batched_mfma_matches_oracle_on_rounded_operands(engine, n, d, metric):
+    """nq >= 5, k <= 128: v_mfma_f32_32x32x16_bf16 tile kernel."""
+    rng = np.random.default_rng(n * 3 + d + metric)
+    X = _rand_unit(rng, n, d)
+    if n > 100:
+        X[n // 2] = X[3]
+        X[n - 1] = X[3]
+    idx = _index(d, metric)
+    idx.add(X)
+    for nq, k in [(5, 10), (19, 1), (33, 32), (64, 100), (100, 33), (256, 10), (300, 64), (1024, 100), (7, 128)]:
+        Q = _rand_unit(rng, nq, d)
+        Q[0] = X[min(3, n - 1)]
+        _check(idx, X, Q, k, metric, atol=ATOL if metric == 0 else 4e-6)
+
+
+def test_every_block_shape_gives_the_same_result(engine):
+    from rag_system_amd import _lib
+    lib = _lib.engine()
+    rng = np.random.default_rng(321)
+    X = _rand_unit(rng, 9_001, 200)        # 200 bf16 = 100 words: K tail for BK = 16 and 32 words
+    X[4500] = X[17]
+    Q = _rand_unit(rng, 70, 200)
+    idx = _index(200)
+    idx.add(X)
+    base = None
+    try:
+        for k in (16, 100):
+            base = None
+            for shape in range(1, 9):
+                for stages in (2, 3):
+                    _lib.check(lib.rag_set_option(b"mfma_shape", shape))
+                    _lib.check(lib.rag_set_option(b"mfma_stages", stages))
+                    D, I = _check(idx, X, Q, k, 0)
+                    if base is None:
+                        base = (D.copy(), I.copy())
+                    assert np.array_equal(I, base[1]) and np.array_equal(D, base[0]), (k, shape, stages)
+    finally:
+        lib.rag_set_option(b"mfma_shape", 0)
+        lib.rag_set_option(b"mfma_stages", 0)
+
+
+def test_stated_bound_and_recall_against_fp32(engine):
+    """Deviation from the exact fp32 scores stays inside the stated bound; recall@k against the
+    exact fp32 top-k is reported (and must be high on separated data)."""
+    rng = np.random.default_rng(2024)
+    n, d, nq, k = 50_000, 384, 64, 10
+    X = _rand_unit(rng, n, d)
+    Q = _rand_unit(rng, nq, d)
+    for qi in range(nq):                    # 10 planted neighbours per query, well separated
+        rows = rng.integers(0, n, size=10)
+        X[rows] = Q[qi] + 0.5 * _rand_unit(rng, 10, d)
+        X[rows] /= np.linalg.norm(X[rows], axis=1, keepdims=True)
+    idx = _index(d)
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    _, I32, D64 = od.flat_search(X, Q, k, 0)
+    X64, Q64 = X.astype(np.float64), Q.astype(np.float64)
+    for qi in range(nq):
+        exact = X64[I[qi]] @ Q64[qi]
+        budget = BF16_BOUND * (np.abs(X64[I[qi]]) @ np.abs(Q64[qi])) + 1e-6
+        assert np.all(np.abs(D[qi] - exact) <= budget), (qi, np.abs(D[qi] - exact).max(), budget.min())
+    recall = np.mean([len(set(I[qi]) & set(I32[qi])) / k for qi in range(nq)])
+    print("bf16 recall@%d vs fp32 exact: %.4f" % (k, recall))
+    assert recall >= 0.99
+    # same corpus, batch of 4 (scan kernel) and one query: identical ids, scores within fp32 noise
+    D4, I4 = idx.search(Q[:4], k)
+    assert np.array_equal(I4, I[:4]) and np.allclose(D4, D[:4], rtol=1e-5, atol=1e-6)
+
+
+def test_config3_shape_10M_x_768_top100_batch1024(engine):
+    """BASELINE config 3 at full size.  Checked through (i) the streaming oracle for three
+    queries and (ii) batch-vs-single consistency: the MFMA batch result must agree with the
+    GEMV scan of the same query (ids equal except near-ties, scores within the fp32 bar)."""
+    n, d, k, nq, seed = 10_000_000, 768, 100, 1024, 1234
+    idx = _index(d)
+    idx._b.add_synthetic(n, seed, 0)
+    Q = od.synth_queries(4321, nq, d)
+    Q[1] = od.synth_rows(seed, 123_456, 1, d)[0]           # a query equal to a corpus row
+    Qr = od.bf16_round(Q)
+    D, I = idx.search(Q, k)
+    assert (I >= 0).all() and (I < n).all()
+    assert all(len(set(r.tolist())) == k for r in I[::37])
+    assert np.all(D[:, :-1] >= D[:, 1:])
+    assert I[1, 0] == 123_456
+    sel = [0, 1, 1023]
+    _, Ir, D64 = od.flat_search_synth(seed, 0, n, d, Qr[sel], k, bf16=True)
+
+    def scorer_for(qs):
+        def f(qi, ids):
+            rows = od.bf16_round(np.stack([od.synth_rows(seed, int(i), 1, d)[0] for i in ids]))
+            return rows.astype(np.float64) @ Qr[qs[qi]].astype(np.float64)
+        return f
+    od.check_topk(D[sel], I[sel], D64, Ir, RTOL, ATOL, scorer_for(sel))
+    D1, I1 = idx.search(Q[sel], k)                          # nq = 3 -> scan kernel
+    od.check_topk(D1, I1, D64, Ir, RTOL, ATOL, scorer_for(sel))

@@ -163,3 +163,18 @@ def test_fusion_oracle_small_cases():
     assert sel[0] == 0 and sel[1] == 2          # the duplicate of the first pick is penalised
     sel = ofu.mmr_selection(E, q, [10, 100, 10, 10], 0.5, 4, 25)
     assert sel == [0, 2]                          # byte budget skips candidates without selecting
+
+
+def test_bf16_rounding_matches_torch_cast():
+    """oracle bf16_rne (shared bit-for-bit by the HIP engine's storage rounding) against an
+    independent implementation: torch's float32 -> bfloat16 cast (round-to-nearest-even)."""
+    import torch
+    rng = np.random.default_rng(11)
+    a = (rng.standard_normal(200_000) * rng.choice([1e-30, 1e-3, 1.0, 1e20], size=200_000)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 1e-40, -1e-45, np.inf, -np.inf,
+                        3.3895314e38, 65504.0], dtype=np.float32)
+    a = np.concatenate([a, special])
+    ref = torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    got = od.bf16_round(a)
+    assert got.tobytes() == ref.tobytes()
+    assert np.isnan(od.bf16_round(np.array([np.nan], dtype=np.float32))[0])
