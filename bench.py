@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = vector rate
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
 def parse():
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
+                    help="row storage (bf16: BASELINE config 3; rows and queries rounded to bfloat16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (A/B runs)")
@@ -114,7 +117,7 @@ def main():
     base = rank * per
     n_local = max(0, min(n, base + per) - base)
 
-    index = faiss.IndexFlatIP(d)
+    index = faiss.IndexFlat(d, faiss.METRIC_INNER_PRODUCT, storage=args.storage)
     index._b.reserve(n_local)
     index._b.add_synthetic(n_local, args.seed, base)
     qgen = faiss.IndexFlatIP(d)
@@ -168,39 +171,45 @@ def main():
         avg_scan_ms = scan_ms / max(n_launch, 1)
         launches_per_step = n_launch / float(args.steps)
         flops = 2.0 * nq * n_local * d * (1.0 / launches_per_step if launches_per_step else 1.0)
-        hbm_bound = nq <= 32
+        bf = args.storage == "bf16"
+        mfma_peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
+        esz = 2 if bf else 4
+        # arithmetic intensity 2*nq/esz flop per byte against the ridge peak_flops / peak_bytes
+        hbm_bound = 2.0 * nq / esz <= mfma_peak * 1e3 / HBM_PEAK_GBS
         if hbm_bound:
             ach = bytes_per_launch / (avg_scan_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None}
         else:
             ach = flops / (avg_scan_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None}
+            roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",
+                    "frac": ach / mfma_peak, "traffic": None}
         roof.update({"kernel": "flat_scan_kernel" if nq < 5 else "flat_mfma_kernel", "avg_launch_ms": avg_scan_ms, "launches": n_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch})
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("rows") == n and tj.get("dim") == d and tj.get("nq") == nq:
+                if (tj.get("rows") == n and tj.get("dim") == d and tj.get("nq") == nq
+                        and tj.get("storage", "f32") == args.storage):
                     roof["traffic"] = tj["hbm_bytes_per_launch"]
                     roof["traffic_source"] = tj.get("source")
             except Exception:
                 pass
         out = {
-            "metric": "QPS, exact IP top-%d over %dM x %d fp32, batch %d" % (k, n // 1_000_000, d, nq),
+            "metric": "QPS, exact IP top-%d over %dM x %d %s, batch %d"
+                      % (k, n // 1_000_000, d, "bf16" if bf else "fp32", nq),
             "value": qps, "unit": "QPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d x %d fp32 L2-normalised synthetic rows (seed %d), IndexFlatIP top-%d, nq=%d"
-                                   % (n, d, args.seed, k, nq),
-                       "rows": n, "dim": d, "k": k, "nq": nq,
+            "vs_baseline": None, "dtype": "bf16" if bf else "f32", "data": "synthetic",
+            "config": {"workload": "%d x %d %s L2-normalised synthetic rows (seed %d), IndexFlatIP top-%d, nq=%d"
+                                   % (n, d, "bf16" if bf else "fp32", args.seed, k, nq),
+                       "rows": n, "dim": d, "k": k, "nq": nq, "storage": args.storage,
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-gather + merge" % world
                                       if world > 1 else "1 GPU"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bf:
             out["cpu_baseline"] = cpu_baseline(args, Q)
         print(json.dumps(out), flush=True)
 

@@ -71,6 +71,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
 }
 
+// benchmarks/mfma_timing.hip builds this header with RAG_MFMA_TIMING: per-segment s_memtime
+// totals of wave 0 of every block are added into g_mfma_timing (never in the product build).
+#ifdef RAG_MFMA_TIMING
+__device__ unsigned long long g_mfma_timing[8];
+#define RAG_TMARK(i)                                            \
+    {                                                           \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        tacc[i] += t_ - tprev;                                  \
+        tprev = t_;                                             \
+    }
+#else
+#define RAG_TMARK(i)
+#endif
+
 template <int WM, int WN, int MT, int BK, int NS, int KS, int METRIC, bool BF>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma_kernel(
     const float* __restrict__ X, long long n, int ld, const float* __restrict__ Qp, int nq, int k, int S,
@@ -173,19 +187,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
         }
     };
     set_tile_offsets();
-    auto issue_loads = [&](int buf) {
+    // One LDS-DMA instruction of the stage being prefetched: part < XQ is an X chunk row, the
+    // rest are Q (or sink) loads.  The prefetch cursor advances with the last part.
+    auto issue_part = [&](int buf, int part) {
         float* xs = Xs + buf * BM * LDS_LD;
         float* qs = Qs + buf * BN * LDS_LD;
         if (pf_tiles_left > 0) {
             const int k0 = pf_ks * BK;
-#pragma unroll
-            for (int it = 0; it < XQ; ++it) {
+            if (part < XQ) {
+                const int it = part;
                 const float* gp = X + xoff[it] + k0;
                 if (ktail && k0 + xcol[it] >= ld) gp = zero16;
                 glds16(gp, xs + (it * NWV + wid) * 256);
-            }
-#pragma unroll
-            for (int it = 0; it < QQ; ++it) {
+            } else {
+                const int it = part - XQ;
                 if (it * NWV + wid < QI) {  // wave-uniform
                     const float* gp = qoff[it] >= 0 ? Qp + qoff[it] + k0 : zero16;
                     if (ktail && k0 + qcol[it] >= ld) gp = zero16;
@@ -194,18 +209,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                     glds16(zero16, dummy);
                 }
             }
-            if (++pf_ks == nk) {
+            if (part == LPS - 1 && ++pf_ks == nk) {
                 pf_ks = 0;
                 pf_row0 += (long long)S * BM;
                 if (--pf_tiles_left > 0) set_tile_offsets();
             }
         } else {
-#pragma unroll
-            for (int it = 0; it < LPS; ++it) glds16(zero16, dummy);
+            glds16(zero16, dummy);
         }
     };
+    auto issue_loads = [&](int buf) {
+#pragma unroll
+        for (int part = 0; part < LPS; ++part) issue_part(buf, part);
+    };
 
+    // accumulators are cleared after each row tile's epilogue (inside its uniform branch), not
+    // by a per-K-step select
     f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     using TK = WaveTopK<float, int, KS>;
 
     // NS-stage ring: stages e .. e+NS-2 are in flight at the top of iteration e.
@@ -216,28 +240,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
     int cur = 0;
     int ks = 0;                                // K step within the current row tile
     long long row0 = (long long)s * BM;        // first row of the current row tile
+#ifdef RAG_MFMA_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     for (long long e = 0; e < total; ++e) {
         // this wave's share of stage e has landed; after the barrier everyone's has, and
         // everyone is done reading the buffer of stage e-1, which the next issue overwrites
         wait_vmcnt<(NS - 2) * LPS>();
+        RAG_TMARK(0)
         __builtin_amdgcn_s_barrier();
-        {
-            int nxt = cur + NS - 1;
-            nxt = nxt >= NS ? nxt - NS : nxt;
-            issue_loads(nxt);
-        }
-        if (ks == 0) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        }
+        RAG_TMARK(1)
         {
             const float* xs = Xs + cur * BM * LDS_LD + wm * BMW * LDS_LD;
             const float* qs = Qs + cur * BN * LDS_LD;
+            const int sw = swz<BK>(li);  // = swz(row): every tile starts at a multiple of 32 rows
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
-                const int sw = swz<BK>(li);  // = swz(row): every tile starts at a multiple of 32 rows
                 const int pc = ((kk * 2 + lh) ^ sw) * 4;
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(qs + (32 * wn + li) * LDS_LD + pc);
                 f32x4 a[MT];
@@ -257,8 +276,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                         for (int t = 0; t < MT; ++t)
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][cc], bq[cc], acc[t], 0, 0, 0);
                 }
+                if (kk == 0) {
+                    // The next stage's loads go out behind the first batch of MFMAs: the waves of
+                    // a CU share one address path (64 B/clk), and a wave that queues there with
+                    // nothing in the matrix pipe leaves its SIMD idle.  (Spreading the loads one
+                    // by one between MFMAs and double-buffering the fragments was measured
+                    // slower: +32 VGPRs spill the 8-wave shapes.)
+                    __builtin_amdgcn_sched_barrier(0);
+                    RAG_TMARK(2)
+                    int nxt = cur + NS - 1;
+                    nxt = nxt >= NS ? nxt - NS : nxt;
+                    issue_loads(nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+        RAG_TMARK(3)
         if (ks == nk - 1) {
             // ---- epilogue of one row tile: threshold filter + list update
             const bool partial = row0 + BM > n;
@@ -322,8 +355,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                     if (li == j) thr = thr_k;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             }
         }
+        RAG_TMARK(4)
         cur = cur + 1 == NS ? 0 : cur + 1;
         if (++ks == nk) {
             ks = 0;
@@ -331,6 +367,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
         }
     }
     wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
+#ifdef RAG_MFMA_TIMING
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_mfma_timing[i], tacc[i]);
+        atomicAdd(&g_mfma_timing[5], (unsigned long long)total);
+        atomicAdd(&g_mfma_timing[6], 1ULL);
+    }
+#endif
 
     // ---- write the lists of every real query: cand[q][s*WM + wm][k]
     __syncthreads();
