@@ -94,3 +94,29 @@ def tfidf_cosine(vectorizer, matrix, query):
     """search_engine.py:284-285: cosine_similarity(vectorizer.transform([query]), matrix)[0]."""
     from sklearn.metrics.pairwise import cosine_similarity
     return cosine_similarity(vectorizer.transform([query]), matrix)[0]
+
+
+def bm25_scores_postings(indptr, rows, tf, idf, doc_len, avgdl, k1, b, term_ids):
+    """BM25OkapiRef.get_scores evaluated on term-major postings: the same float64 operations in
+    the same order for every (document, query term) with tf > 0; documents without the term
+    receive idf * (0 * (k1+1) / (0 + ...)) = +0.0 in get_scores, which leaves the sum unchanged.
+    tests/test_oracle_cpu.py pins it bit-for-bit to BM25OkapiRef.  Used for full-size checks
+    where a million Python dicts would not fit."""
+    score = np.zeros(len(doc_len))
+    dl = np.asarray(doc_len)
+    for t in term_ids:
+        lo, hi = int(indptr[t]), int(indptr[t + 1])
+        r = rows[lo:hi]
+        q_freq = tf[lo:hi]
+        score[r] += idf[t] * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * dl[r] / avgdl)))
+    return score
+
+
+def tfidf_scores_postings(indptr, rows, val, term_ids, weights, n_rows):
+    """cosine_similarity(q, M)[0] on term-major postings of the row-normalised matrix: scipy's
+    csr_matmat adds w_t * M[doc, t] term by term in ascending term order."""
+    score = np.zeros(n_rows)
+    for t, w in zip(term_ids, weights):
+        lo, hi = int(indptr[t]), int(indptr[t + 1])
+        score[rows[lo:hi]] += w * val[lo:hi]
+    return score

@@ -138,11 +138,14 @@ class BM25Okapi:
                      np.fromiter((f for r in post_tf for f in r), dtype=np.float64, count=int(df.sum())))
 
     @classmethod
-    def from_term_ids(cls, doc_indptr, doc_terms, k1=1.5, b=0.75, epsilon=0.25):
+    def from_term_ids(cls, doc_indptr, doc_terms, k1=1.5, b=0.75, epsilon=0.25, keep_postings=False):
         """Corpus given as integer tokens: document i = doc_terms[doc_indptr[i]:doc_indptr[i+1]].
         Same statistics as the list-of-tokens constructor (token = the integer), built with
-        numpy so that million-document synthetic corpora index in seconds."""
+        numpy so that million-document synthetic corpora index in seconds.
+        keep_postings: keep the host copy of the term-major postings as self.postings =
+        (indptr, rows, tf) (benchmarks cross-check full-size results with it)."""
         self = cls.__new__(cls)
+        self._keep_postings = keep_postings
         self.k1, self.b, self.epsilon, self.tokenizer = k1, b, epsilon, None
         doc_indptr = np.asarray(doc_indptr, dtype=np.int64)
         doc_terms = np.asarray(doc_terms, dtype=np.int64)
@@ -190,6 +193,8 @@ class BM25Okapi:
             idf[t] = eps
         self.idf = {w: float(idf[t]) for t, w in enumerate(words)}
         self._idf_arr = idf
+        if getattr(self, "_keep_postings", False):
+            self.postings = (indptr, rows, tf)
         self._csc = make_csc(len(words), n, indptr, rows, tf)
         self._csc.bm25_set(idf, np.asarray(self.doc_len, dtype=np.int32), self.avgdl, self.k1, self.b)
 

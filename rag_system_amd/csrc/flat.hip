@@ -227,12 +227,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
     const long long C = (long long)nlists * k;
     const float* ck = cand_key + q * C;
     const int* ci = cand_id + q * C;
+    __shared__ float red[MERGE_WAVES];
+    const float floor_key = block_max_kth<float, MERGE_WAVES>(
+        [&](int l) {
+            const long long o = (long long)l * k + (k - 1);
+            return ci[o] != IdPad<int>::v() ? ck[o] : Lowest<float>::v();
+        },
+        nlists, red);
     WaveTopK<float, int, KS> tk;
     block_merge<float, int, KS, MERGE_WAVES>(
         [&](long long c, float& key, int& id) {
             key = ck[c];
             id = ci[c];
-            return id != IdPad<int>::v();
+            return id != IdPad<int>::v() && key >= floor_key;
         },
         C, k, tk, mk, mi);
     if (threadIdx.x < 64) {
@@ -261,6 +268,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
     const long long q = blockIdx.x;
     const long long C = (long long)nlists * k;
     const bool ip = metric == RAG_METRIC_IP;
+    __shared__ float red[MERGE_WAVES];
+    const float floor_key = block_max_kth<float, MERGE_WAVES>(
+        [&](int l) {
+            const long long o = ((long long)l * nq + q) * k + (k - 1);
+            return Il[o] >= 0 ? (ip ? Dl[o] : -Dl[o]) : Lowest<float>::v();
+        },
+        nlists, red);
     WaveTopK<float, long long, KS> tk;
     block_merge<float, long long, KS, MERGE_WAVES>(
         [&](long long c, float& key, long long& id) {
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
             id = Il[o];
             const float v = Dl[o];
             key = ip ? v : -v;
-            return id >= 0;
+            return id >= 0 && key >= floor_key;
         },
         C, k, tk, mk, mi);
     if (threadIdx.x < 64) {

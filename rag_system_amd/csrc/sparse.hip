@@ -100,12 +100,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const d
     __shared__ double mk[(MERGE_WAVES - 1) * KS * 64];
     __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
     const long long C = (long long)nlists * k;
+    __shared__ double red[MERGE_WAVES];
+    const double floor_key = block_max_kth<double, MERGE_WAVES>(
+        [&](int l) {
+            const long long o = (long long)l * k + (k - 1);
+            return cand_id[o] != IdPad<int>::v() ? cand_key[o] : Lowest<double>::v();
+        },
+        nlists, red);
     WaveTopK<double, int, KS> tk;
     block_merge<double, int, KS, MERGE_WAVES>(
         [&](long long c, double& key, int& id) {
             key = cand_key[c];
             id = cand_id[c];
-            return id != IdPad<int>::v();
+            return id != IdPad<int>::v() && key >= floor_key;
         },
         C, k, tk, mk, mi);
     if (threadIdx.x < 64) {
@@ -122,36 +129,98 @@ __global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const d
     }
 }
 
-// rank[i] = #{ j : s_j > s_q(i)  or  (s_j == s_q(i) and j < q(i)) }  for nq queried rows.
+// rank[i] = #{ j : s_j > s_q(i)  or  (s_j == s_q(i) and j < q(i)) }  for nq queried rows, i.e.
+// the position of row q(i) in the stable descending sort of all n scores.
+//   rank_prep_kernel   sorts the nq queried (score, row) pairs best-first (rank by counting).
+//   rank_hist_kernel   every row j finds b(j) = number of queried pairs ranked ahead of (s_j, j)
+//                      by binary search and bumps histogram bin b(j): row j precedes exactly
+//                      the queried pairs at sorted positions >= b(j) (except itself).
+//   rank_final_kernel  rank of sorted position p = hist[0] + ... + hist[p] - 1 (minus itself).
+// One pass over the score vector whatever nq is.
 constexpr int RANK_MAXQ = 1024;
-__global__ __launch_bounds__(256) void rank_kernel(const double* __restrict__ score, long long n, int nq,
-                                                   const long long* __restrict__ qrow,
-                                                   unsigned long long* __restrict__ rank) {
-    __shared__ double qs[RANK_MAXQ];
-    __shared__ long long qr[RANK_MAXQ];
-    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
-        qr[i] = qrow[i];
-        qs[i] = score[qrow[i]];
+
+__device__ __forceinline__ bool pair_ahead(double ka, long long ia, double kb, long long ib) {
+    return (ka > kb) || (ka == kb && ia < ib);
+}
+
+__global__ __launch_bounds__(RANK_MAXQ) void rank_prep_kernel(const double* __restrict__ score, int nq,
+                                                              const long long* __restrict__ qrow,
+                                                              double* __restrict__ skey, long long* __restrict__ srow,
+                                                              int* __restrict__ pos_of, unsigned long long* __restrict__ hist) {
+    __shared__ double ks[RANK_MAXQ];
+    __shared__ long long rs[RANK_MAXQ];
+    const int i = threadIdx.x;
+    if (i < nq) {
+        rs[i] = qrow[i];
+        ks[i] = score[qrow[i]];
     }
+    if (i < nq) hist[i] = 0;
+    if (i == 0) hist[nq] = 0;
+    __syncthreads();
+    if (i < nq) {
+        const double k = ks[i];
+        const long long r = rs[i];
+        int pos = 0;
+        for (int j = 0; j < nq; ++j)  // a row queried twice: the earlier query sorts first
+            pos += (pair_ahead(ks[j], rs[j], k, r) || (ks[j] == k && rs[j] == r && j < i)) ? 1 : 0;
+        skey[pos] = k;
+        srow[pos] = r;
+        pos_of[i] = pos;
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_hist_kernel(const double* __restrict__ score, long long n, int nq,
+                                                        const double* __restrict__ skey,
+                                                        const long long* __restrict__ srow,
+                                                        unsigned long long* __restrict__ hist) {
+    __shared__ double ks[RANK_MAXQ];
+    __shared__ long long rs[RANK_MAXQ];
+    __shared__ unsigned int h[RANK_MAXQ + 1];
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+        ks[i] = skey[i];
+        rs[i] = srow[i];
+    }
+    for (int i = threadIdx.x; i <= nq; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const long long stride = (long long)gridDim.x * blockDim.x;
-    const int lane = threadIdx.x & 63;
-    // every thread of a wave runs the same trip count so the shuffles below are uniform
-    const long long j0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long trips = (n + stride - 1) / stride;
-    for (int i = 0; i < nq; ++i) {
-        const double s = qs[i];
-        const long long r = qr[i];
-        unsigned int cnt = 0;
-        long long j = j0;
-        for (long long t = 0; t < trips; ++t, j += stride)
-            if (j < n) {
-                const double v = score[j];
-                cnt += (v > s || (v == s && j < r)) ? 1u : 0u;
-            }
-        for (int dist = 32; dist >= 1; dist >>= 1) cnt += __shfl_xor(cnt, dist);
-        if (lane == 0 && cnt) atomicAdd(&rank[i], (unsigned long long)cnt);
+    int run_bin = -1;
+    unsigned int run_cnt = 0;  // consecutive rows of a thread mostly fall into one bin
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const double v = score[j];
+        int lo = 0, hi = nq;  // first sorted position whose pair is NOT ahead of (v, j)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pair_ahead(ks[mid], rs[mid], v, j)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo == run_bin) {
+            ++run_cnt;
+        } else {
+            if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+            run_bin = lo;
+            run_cnt = 1;
+        }
     }
+    if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nq; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+__global__ __launch_bounds__(RANK_MAXQ) void rank_final_kernel(const unsigned long long* __restrict__ hist, int nq,
+                                                               const int* __restrict__ pos_of,
+                                                               unsigned long long* __restrict__ rank) {
+    __shared__ unsigned long long pre[RANK_MAXQ];
+    const int i = threadIdx.x;
+    if (i == 0) {
+        unsigned long long run = 0;
+        for (int p = 0; p < nq; ++p) {
+            run += hist[p];
+            pre[p] = run;
+        }
+    }
+    __syncthreads();
+    if (i < nq) rank[i] = pre[pos_of[i]] - 1ULL;
 }
 
 __global__ void gather_kernel(const double* __restrict__ score, int nq, const long long* __restrict__ qrow,
@@ -178,6 +247,7 @@ struct rag_csc {
     double* cand_key = nullptr; int* cand_id = nullptr; int64_t cand_cap = 0;
     double* out_D = nullptr; long long* out_I = nullptr; int64_t out_cap = 0;
     long long* rk_rows = nullptr; unsigned long long* rk_out = nullptr;
+    double* rk_skey = nullptr; long long* rk_srow = nullptr; int* rk_pos = nullptr; unsigned long long* rk_hist = nullptr;
     std::mutex mu;
 };
 
@@ -269,6 +339,10 @@ int rag_csc_create(int64_t n_terms, int64_t n_rows, const int64_t* indptr, const
     if (e == hipSuccess) e = hipMalloc(&h->score, (size_t)std::max<int64_t>(n_rows, 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->rk_rows, RANK_MAXQ * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->rk_out, RANK_MAXQ * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->rk_skey, RANK_MAXQ * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->rk_srow, RANK_MAXQ * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(&h->rk_pos, RANK_MAXQ * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->rk_hist, (RANK_MAXQ + 1) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         rag_csc_free(h);
         return fail(e == hipErrorOutOfMemory ? RAG_ERR_OOM : RAG_ERR_HIP, "rag_csc_create: %s", hipGetErrorString(e));
@@ -290,6 +364,10 @@ void rag_csc_free(rag_csc_t* h) {
     (void)hipFree(h->out_I);
     (void)hipFree(h->rk_rows);
     (void)hipFree(h->rk_out);
+    (void)hipFree(h->rk_skey);
+    (void)hipFree(h->rk_srow);
+    (void)hipFree(h->rk_pos);
+    (void)hipFree(h->rk_hist);
     delete h;
 }
 
@@ -378,10 +456,12 @@ int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks
     for (int q0 = 0; q0 < n_query; q0 += RANK_MAXQ) {
         const int nq = std::min(RANK_MAXQ, n_query - q0);
         RAG_HIP(hipMemcpyAsync(h->rk_rows, rows + q0, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
-        RAG_HIP(hipMemsetAsync(h->rk_out, 0, (size_t)nq * sizeof(unsigned long long), st));
-        long long nb = (h->n_rows + 1023) / 1024;
+        long long nb = (h->n_rows + 2047) / 2048;
         nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
-        rank_kernel<<<(unsigned)nb, 256, 0, st>>>(h->score, (long long)h->n_rows, nq, h->rk_rows, h->rk_out);
+        rank_prep_kernel<<<1, RANK_MAXQ, 0, st>>>(h->score, nq, h->rk_rows, h->rk_skey, h->rk_srow, h->rk_pos, h->rk_hist);
+        rank_hist_kernel<<<(unsigned)nb, 256, 0, st>>>(h->score, (long long)h->n_rows, nq, h->rk_skey, h->rk_srow,
+                                                      h->rk_hist);
+        rank_final_kernel<<<1, RANK_MAXQ, 0, st>>>(h->rk_hist, nq, h->rk_pos, h->rk_out);
         RAG_HIP(hipGetLastError());
         RAG_HIP(hipMemcpyAsync(ranks + q0, h->rk_out, (size_t)nq * sizeof(long long), hipMemcpyDeviceToHost, st));
         RAG_HIP(hipStreamSynchronize(st));

@@ -21,6 +21,32 @@ template <typename T> struct IdPad;
 template <> struct IdPad<int>       { static __device__ __forceinline__ int       v() { return INT_MAX; } };
 template <> struct IdPad<long long> { static __device__ __forceinline__ long long v() { return LLONG_MAX; } };
 
+// Cross-lane moves without the LDS crossbar: v_readlane_b32 for a wave-uniform source lane,
+// v_mov_b32_dpp wave_shr:1 for "lane i takes lane i-1" (lane 0 keeps its own value).  A
+// ds_bpermute round trip costs ~100 cycles; the list insert below is a chain of such moves.
+__device__ __forceinline__ int bcast_lane(int v, int uniform_lane) { return __builtin_amdgcn_readlane(v, uniform_lane); }
+__device__ __forceinline__ float bcast_lane(float v, int uniform_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), uniform_lane));
+}
+__device__ __forceinline__ long long bcast_lane(long long v, int uniform_lane) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFLL), uniform_lane);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), uniform_lane);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ double bcast_lane(double v, int uniform_lane) {
+    return __longlong_as_double(bcast_lane(__double_as_longlong(v), uniform_lane));
+}
+__device__ __forceinline__ int shift_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ float shift_up1(float v) { return __int_as_float(shift_up1(__float_as_int(v))); }
+__device__ __forceinline__ long long shift_up1(long long v) {
+    const int lo = shift_up1((int)(v & 0xFFFFFFFFLL));
+    const int hi = shift_up1((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ double shift_up1(double v) {
+    return __longlong_as_double(shift_up1(__double_as_longlong(v)));
+}
+
 template <typename KeyT, typename IdT, int KS>
 struct WaveTopK {
     KeyT key[KS];
@@ -45,11 +71,11 @@ struct WaveTopK {
         for (int s = 0; s < KS; ++s) pos += __popcll(__ballot(ahead(key[s], id[s], nk, ni)));
 #pragma unroll
         for (int s = KS - 1; s >= 0; --s) {
-            KeyT uk = __shfl_up(key[s], 1);
-            IdT ui = __shfl_up(id[s], 1);
+            KeyT uk = shift_up1(key[s]);
+            IdT ui = shift_up1(id[s]);
             if (s > 0) {
-                KeyT ck = __shfl(key[s - 1], 63);
-                IdT ci = __shfl(id[s - 1], 63);
+                KeyT ck = bcast_lane(key[s - 1], 63);
+                IdT ci = bcast_lane(id[s - 1], 63);
                 if (lane == 0) {
                     uk = ck;
                     ui = ci;
@@ -72,8 +98,8 @@ struct WaveTopK {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             if (s == (p >> 6)) {
-                tk = __shfl(key[s], p & 63);
-                ti = __shfl(id[s], p & 63);
+                tk = bcast_lane(key[s], p & 63);
+                ti = bcast_lane(id[s], p & 63);
             }
     }
 };
@@ -88,8 +114,8 @@ __device__ __forceinline__ void wave_offer(WaveTopK<KeyT, IdT, KS>& tk, int k, K
     while (m) {
         const int l = __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
-        const KeyT nk = __shfl(ck, l);
-        const IdT ni = __shfl(ci, l);
+        const KeyT nk = bcast_lane(ck, l);
+        const IdT ni = bcast_lane(ci, l);
         if (TK::ahead(nk, ni, thr_k, thr_i)) {
             tk.insert(nk, ni, lane);
             tk.kth(k, thr_k, thr_i);
@@ -119,6 +145,30 @@ __device__ __forceinline__ float wave_multi_reduce(float (&v)[N], int lane) {
     return v[0];
 }
 
+// Largest k-th key over `nlists` sorted k-lists (kth_of_list(l) = key at position k-1 of list l,
+// Lowest if that position is a pad).  The list that holds it has k entries >= this value, so
+// no candidate below it can reach the merged top-k: merges drop those before any insertion.
+// red: LDS scratch of NWAVES keys.  Every thread of the block must call.
+template <typename KeyT, int NWAVES, class KthLoader>
+__device__ __forceinline__ KeyT block_max_kth(KthLoader kth_of_list, int nlists, KeyT* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    KeyT m = Lowest<KeyT>::v();
+    for (int l = tid; l < nlists; l += NWAVES * 64) {
+        const KeyT v = kth_of_list(l);
+        m = v > m ? v : m;
+    }
+    for (int dist = 32; dist >= 1; dist >>= 1) {
+        const KeyT o = __shfl_xor(m, dist);
+        m = o > m ? o : m;
+    }
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    KeyT r = red[0];
+    for (int w = 1; w < NWAVES; ++w) r = red[w] > r ? red[w] : r;
+    __syncthreads();
+    return r;
+}
+
 // Block-wide merge of C candidate (key, id) pairs into one sorted k-list held by wave 0 of a
 // block of NWAVES waves.  `load(c, key, id)` returns the validity of candidate c in [0, C).
 // mk / mi: LDS scratch of (NWAVES-1)*KS*64 entries each.  Every thread of the block must call.
@@ -129,13 +179,22 @@ __device__ __forceinline__ void block_merge(Loader load, long long C, int k, Wav
     KeyT thr_k = Lowest<KeyT>::v();
     IdT thr_i = IdPad<IdT>::v();
     tk.init();
-    for (long long base = (long long)wid * 64; base < C; base += NWAVES * 64) {
-        const long long c = base + lane;
-        KeyT ck = Lowest<KeyT>::v();
-        IdT ci = IdPad<IdT>::v();
-        bool valid = false;
-        if (c < C) valid = load(c, ck, ci);
-        wave_offer<KeyT, IdT, KS>(tk, k, thr_k, thr_i, ck, ci, valid, lane);
+    // U independent candidate loads are in flight before the first is offered: one round trip to
+    // memory per U*64 candidates instead of one per 64 (the loop is latency-bound otherwise).
+    constexpr int U = 8;
+    for (long long base = (long long)wid * 64 * U; base < C; base += (long long)NWAVES * 64 * U) {
+        KeyT ck[U];
+        IdT ci[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long c = base + u * 64 + lane;
+            ck[u] = Lowest<KeyT>::v();
+            ci[u] = IdPad<IdT>::v();
+            valid[u] = c < C ? load(c, ck[u], ci[u]) : false;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) wave_offer<KeyT, IdT, KS>(tk, k, thr_k, thr_i, ck[u], ci[u], valid[u], lane);
     }
     if (wid > 0) {
 #pragma unroll

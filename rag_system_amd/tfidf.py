@@ -48,6 +48,16 @@ class TfidfScorer:
         s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
         return s
 
+    def top_k_from_row(self, indices, data, k):
+        """top_k() for an already vectorised query row (k <= MAX_FUSED_K)."""
+        from scipy.sparse import csr_matrix
+        indices = np.asarray(indices, dtype=np.int32)
+        qv = csr_matrix((np.asarray(data, dtype=np.float64), indices, np.array([0, len(indices)], dtype=np.int32)),
+                        shape=(1, self.n_terms))
+        t, w = self._normalized(qv)
+        _, D, I = self._csc.tfidf_scores(t, w, want_scores=False, k=min(int(k), self.n_docs))
+        return I, D
+
     def scores(self, query):
         """cosine_similarity(vectorizer.transform([query]), matrix)[0] as float64 (n_docs,)."""
         t, w = self._query(query)

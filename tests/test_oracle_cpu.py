@@ -178,3 +178,26 @@ def test_bf16_rounding_matches_torch_cast():
     got = od.bf16_round(a)
     assert got.tobytes() == ref.tobytes()
     assert np.isnan(od.bf16_round(np.array([np.nan], dtype=np.float32))[0])
+
+
+def test_postings_form_of_bm25_equals_dict_form():
+    """oracle.sparse.bm25_scores_postings (vectorised, used at 1M documents) is bit-identical to
+    the rank_bm25 restatement BM25OkapiRef on a corpus both can hold."""
+    docs = zipf_corpus(400, 300, 60, seed=3)
+    ref = osp.BM25OkapiRef(docs, k1=1.0, b=0.65)
+    vocab = {w: i for i, w in enumerate(ref.idf)}
+    post = {}
+    for di, d in enumerate(docs):
+        for w, f in ref.doc_freqs[di].items():
+            post.setdefault(vocab[w], []).append((di, f))
+    indptr = np.zeros(len(vocab) + 1, np.int64)
+    rows, tf = [], []
+    for t in range(len(vocab)):
+        indptr[t + 1] = indptr[t] + len(post[t])
+        rows += [p[0] for p in post[t]]
+        tf += [float(p[1]) for p in post[t]]
+    idf = np.array([ref.idf[w] for w in vocab])
+    for q in zipf_queries(8, 300, seed=4):
+        tids = [vocab[w] for w in q if w in vocab]
+        got = osp.bm25_scores_postings(indptr, np.array(rows), np.array(tf), idf, ref.doc_len, ref.avgdl, 1.0, 0.65, tids)
+        assert got.tobytes() == ref.get_scores(q).tobytes()
