@@ -1,0 +1,23 @@
+# Round-1 profiles: kernel-trace stats and PMC passes, each in its own rocprofv3 run.
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/prof_r01; rm -rf $O; mkdir -p $O
+run() { name=$1; shift; timeout -s KILL 240 rocprofv3 "$@" > $O/$name.log 2>&1 || echo "$name failed"; }
+NQ1="bench.py --no-cpu-baseline --steps 50 --warmup 5"
+NQ1024="bench.py --no-cpu-baseline --nq 1024 --steps 3 --warmup 1"
+C3="bench.py --no-cpu-baseline --storage bf16 --dim 768 --k 100 --nq 1024 --steps 3 --warmup 1"
+run nq1_stats --kernel-trace --stats -d $O/nq1_stats --output-format csv -- python3 $NQ1
+run nq1_fetch --pmc FETCH_SIZE -d $O/nq1_fetch --output-format csv -- python3 $NQ1
+run nq1_write --pmc WRITE_SIZE -d $O/nq1_write --output-format csv -- python3 $NQ1
+run nq1024_stats --kernel-trace --stats -d $O/nq1024_stats --output-format csv -- python3 $NQ1024
+run nq1024_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/nq1024_sq --output-format csv -- python3 $NQ1024
+run nq1024_grbm --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA -d $O/nq1024_grbm --output-format csv -- python3 $NQ1024
+run nq1024_fetch --pmc FETCH_SIZE -d $O/nq1024_fetch --output-format csv -- python3 $NQ1024
+run c3_stats --kernel-trace --stats -d $O/c3_stats --output-format csv -- python3 $C3
+run c3_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/c3_sq --output-format csv -- python3 $C3
+run c3_grbm --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA -d $O/c3_grbm --output-format csv -- python3 $C3
+run hyb_stats --kernel-trace --stats -d $O/hyb_stats --output-format csv -- python3 benchmarks/bench_hybrid.py --no-cpu --queries 20
+for d in nq1_fetch nq1_write; do python3 benchmarks/pmc_summary.py $O/$d flat_scan_kernel --skip 5 > $O/$d.json; done
+for d in nq1024_sq nq1024_grbm nq1024_fetch c3_sq c3_grbm; do python3 benchmarks/pmc_summary.py $O/$d flat_mfma_kernel --skip 1 > $O/$d.json; done
+# keep only the summaries (traces are large)
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
+ls -R $O | head -60
