@@ -42,7 +42,9 @@ extern "C" {
 #define RAG_METRIC_L2 1   /* faiss.METRIC_L2 (squared), IndexFlatL2   */
 
 #define RAG_DTYPE_F32  0  /* rows stored as float32 (faiss IndexFlat)      */
-#define RAG_DTYPE_BF16 1  /* rows stored as bfloat16 (RNE), fp32 accumulate */
+#define RAG_DTYPE_BF16 1  /* rows stored as bfloat16 (round-to-nearest-even); queries are rounded
+                             the same way at search time; exact products, fp32 accumulate.  No
+                             counterpart in the reference (BASELINE.json config 3).            */
 
 /* Largest k one fused scan+select pass serves; larger k (up to RAG_MAX_K_TOTAL) is served in
  * ceil(k/256) passes over the matrix.  (faiss-gpu's own limit is 2048; the reference issues
@@ -120,7 +122,8 @@ int rag_flat_profiling(rag_flat_t* h, int enable);
  * (ntotal*d*sizeof(elem)). */
 int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double* bytes_per_launch);
 /* Tuning knobs for A/B runs in one process: "scan_blocks", "scan_nt",
- * "scan_rows", "mfma_min_nq", "mfma_shape", "mfma_bpc", "mfma_stages". Unknown name -> RAG_ERR_INVALID_ARG. */
+ * "scan_rows", "mfma_min_nq", "mfma_shape" (1..8), "mfma_bpc", "mfma_stages" (2..3).
+ * Unknown name -> RAG_ERR_INVALID_ARG.  Results never depend on them (tests/test_flat_gpu.py). */
 int rag_set_option(const char* name, int64_t value);
 
 /* ---- sparse scoring (BM25Okapi, TF-IDF cosine) ------------------------- */
