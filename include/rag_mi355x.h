@@ -122,7 +122,8 @@ int rag_flat_profiling(rag_flat_t* h, int enable);
  * (ntotal*d*sizeof(elem)). */
 int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double* bytes_per_launch);
 /* Tuning knobs for A/B runs in one process: "scan_blocks", "scan_nt",
- * "scan_rows", "mfma_min_nq", "mfma_shape" (1..8), "mfma_bpc", "mfma_stages" (2..3).
+ * "scan_rows", "mfma_min_nq", "mfma_shape" (1..8), "mfma_bpc", "mfma_stages" (2..3),
+ * "mfma_filter_k", "mfma_filter_min_rows" (when the batch kernel uses thresholds + append buffers).
  * Unknown name -> RAG_ERR_INVALID_ARG.  Results never depend on them (tests/test_flat_gpu.py). */
 int rag_set_option(const char* name, int64_t value);
 

@@ -23,6 +23,7 @@
 #include "topk.h"
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 namespace {
@@ -220,10 +221,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void flat_scan_kernel(
 template <int KS, int METRIC>
 __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
     const float* __restrict__ cand_key, const int* __restrict__ cand_id, int nlists, int k,
-    float* __restrict__ D, long long* __restrict__ I, long long id_base, int out_stride, int out_off) {
+    float* __restrict__ D, long long* __restrict__ I, long long id_base, int out_stride, int out_off,
+    const int* __restrict__ only_if) {
     __shared__ float mk[(MERGE_WAVES - 1) * KS * 64];
     __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
     const long long q = blockIdx.x;
+    if (only_if != nullptr && only_if[q] == 0) return;  // redo pass: only the queries that failed
     const long long C = (long long)nlists * k;
     const float* ck = cand_key + q * C;
     const int* ci = cand_id + q * C;
@@ -296,6 +299,48 @@ __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
                 const float key = tk.key[s];
                 D[q * k + p] = pad ? (ip ? -FLT_MAX : FLT_MAX) : (ip ? key : -key);
                 I[q * k + p] = pad ? -1LL : tk.id[s];
+            }
+        }
+    }
+}
+
+// Filter mode of the MFMA path: top-k of one query's append buffer (unsorted; every row scoring
+// >= the query's threshold).  count in [k, cap] -> the buffer holds the exact global top-k;
+// otherwise the query is flagged for the list-mode redo pass.
+template <int KS, int METRIC>
+__global__ __launch_bounds__(MERGE_THREADS) void filter_select_kernel(
+    const float* __restrict__ cand_key, const int* __restrict__ cand_id, const unsigned int* __restrict__ counts,
+    int cap, int k, float* __restrict__ D, long long* __restrict__ I, long long id_base, int* __restrict__ nfail,
+    int* __restrict__ fail) {
+    __shared__ float mk[(MERGE_WAVES - 1) * KS * 64];
+    __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
+    const long long q = blockIdx.x;
+    const unsigned int cnt = counts[q];
+    const bool ok = cnt >= (unsigned int)k && cnt <= (unsigned int)cap;
+    if (threadIdx.x == 0) {
+        fail[q] = ok ? 0 : 1;
+        if (!ok) atomicAdd(nfail, 1);
+    }
+    if (!ok) return;
+    const float* ck = cand_key + q * cap;
+    const int* ci = cand_id + q * cap;
+    WaveTopK<float, int, KS> tk;
+    block_merge<float, int, KS, MERGE_WAVES>(
+        [&](long long c, float& key, int& id) {
+            key = ck[c];
+            id = ci[c];
+            return true;
+        },
+        (long long)cnt, k, tk, mk, mi);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int p = s * 64 + lane;
+            if (p < k) {
+                const float key = tk.key[s];
+                D[q * k + p] = METRIC == RAG_METRIC_IP ? key : -key;
+                I[q * k + p] = id_base + (long long)tk.id[s];
             }
         }
     }
@@ -423,6 +468,11 @@ struct rag_flat {
     float* ws_fk = nullptr;  int64_t ws_fk_cap = 0;    // per-query floors for k > 256 passes
     int* ws_fi = nullptr;    int64_t ws_fi_cap = 0;
     float* ws_qn = nullptr;  int64_t ws_qn_cap = 0;    // ||q||^2 (L2, MFMA path)
+    // MFMA filter mode: sample results, thresholds, counters [nq] + nfail [1] + fail flags [nq]
+    float* ws_sD = nullptr;  int64_t ws_sD_cap = 0;
+    long long* ws_sI = nullptr; int64_t ws_sI_cap = 0;
+    float* ws_thr = nullptr; int64_t ws_thr_cap = 0;
+    int* ws_cnt = nullptr;   int64_t ws_cnt_cap = 0;
     float* zero16 = nullptr;                           // 64 B of zeros (MFMA tile padding source)
     float* xnorm = nullptr;  int64_t xnorm_cap = 0;    // ||x||^2 per row (L2, MFMA path), lazily filled
     int64_t norm_valid = 0;
@@ -569,7 +619,7 @@ scan_fn_t pick_scan(const ScanCfg& c) {
     return pick_scan1<4, 4>(c.KS, c.metric, c.nt, c.bf);
 }
 
-typedef void (*merge_fn_t)(const float*, const int*, int, int, float*, long long*, long long, int, int);
+typedef void (*merge_fn_t)(const float*, const int*, int, int, float*, long long*, long long, int, int, const int*);
 merge_fn_t pick_merge(int KS, int metric) {
     if (metric == RAG_METRIC_IP) {
         if (KS == 1) return flat_merge_kernel<1, RAG_METRIC_IP>;
@@ -617,9 +667,26 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
 
     MfmaPlan plan;
     if (nq >= opt.mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan)) {
-        rc = grow(h->ws_key, h->ws_key_cap, nq * plan.nlists * k);
+        // Filter mode for larger k on large shards: a 1/FILTER_STEP sample of the row tiles gives
+        // each query a threshold (its j-th best sample score), one pass appends every row at or
+        // above it, and the top-k of the few hundred appended rows is the exact result.  With
+        // E[count] = j*step and sd ~ step*sqrt(j), j = (2 + sqrt(4 + k/step))^2 puts k four
+        // deviations below the mean; queries that still end outside [k, cap] (ties, skewed row
+        // order) are redone by the list-mode kernel, which otherwise returns at once.
+        constexpr int FILTER_STEP = 32;
+        const double root = 2.0 + std::sqrt(4.0 + (double)k / FILTER_STEP);
+        const int j = std::min(64, (int)std::ceil(root * root));
+        int cap = 1024;
+        while (cap < j * FILTER_STEP + 8 * FILTER_STEP * (int)std::ceil(std::sqrt((double)j))) cap *= 2;
+        MfmaPlan ps, pf;
+        const bool filter = k >= opt.mfma_filter_k && n >= opt.mfma_filter_min_rows &&
+                            mfma_plan(std::max<long long>(1, n / FILTER_STEP), nq, j, bf, &ps) &&
+                            mfma_plan_filter(n, nq, bf, cap, &pf);
+        int64_t need = nq * plan.nlists * k;
+        if (filter) need = std::max<int64_t>(need, std::max<int64_t>(nq * ps.nlists * j, nq * (int64_t)cap));
+        rc = grow(h->ws_key, h->ws_key_cap, need);
         if (rc) return rc;
-        rc = grow(h->ws_id, h->ws_id_cap, nq * plan.nlists * k);
+        rc = grow(h->ws_id, h->ws_id_cap, need);
         if (rc) return rc;
         if (h->metric == RAG_METRIC_L2) {
             if (h->xnorm_cap < h->cap) {  // follow the arena
@@ -642,6 +709,18 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             rc = mfma_row_norms(h->ws_q, ld, false, 0, nq, h->ws_qn, st);
             if (rc) return rc;
         }
+        if (filter) {
+            rc = grow(h->ws_sD, h->ws_sD_cap, nq * j);
+            if (rc) return rc;
+            rc = grow(h->ws_sI, h->ws_sI_cap, nq * j);
+            if (rc) return rc;
+            rc = grow(h->ws_thr, h->ws_thr_cap, nq);
+            if (rc) return rc;
+            rc = grow(h->ws_fi, h->ws_fi_cap, nq);
+            if (rc) return rc;
+            rc = grow(h->ws_cnt, h->ws_cnt_cap, 2 * nq + 1);
+            if (rc) return rc;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->prof) {
             if (!h->ev_free.empty()) {
@@ -659,16 +738,66 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             RAG_HIP(hipMemsetAsync(h->zero16, 0, 64, st));
         }
         // the kernel moves 16-byte chunks: both operands are addressed in 4-byte words
-        rc = mfma_launch(plan, reinterpret_cast<const float*>(h->x), (long long)n, ld * h->esz / 4,
-                         bf ? reinterpret_cast<const float*>(h->ws_qb) : h->ws_q, (int)nq, k, h->metric, h->ws_key,
-                         h->ws_id, h->xnorm, h->ws_qn, h->zero16, st);
+        const float* Xw = reinterpret_cast<const float*>(h->x);
+        const float* Qw = bf ? reinterpret_cast<const float*>(h->ws_qb) : h->ws_q;
+        const int ldw = ld * h->esz / 4;
+        merge_fn_t mf = pick_merge(KS, h->metric);
+        if (!filter) {
+            rc = mfma_launch(plan, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                             h->ws_qn, h->zero16, st);
+            if (rc) return rc;
+            if (h->prof) {
+                RAG_HIP(hipEventRecord(e1, st));
+                h->ev_used.emplace_back(e0, e1);
+            }
+            mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.nlists, k, D_dev, I_dev,
+                                                       (long long)id_base, k, 0, nullptr);
+            RAG_HIP(hipGetLastError());
+            return RAG_OK;
+        }
+        // 1. sample pass (list mode over every FILTER_STEP-th row tile) -> j best per query -> threshold
+        ps.tile_step = FILTER_STEP;
+        rc = mfma_launch(ps, Xw, (long long)n, ldw, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
+                         h->zero16, st);
+        if (rc) return rc;
+        pick_merge(1, h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, ps.nlists, j, h->ws_sD,
+                                                                        h->ws_sI, 0LL, j, 0, nullptr);
+        make_floor_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, st>>>(h->ws_sD, h->ws_sI, nq, j, j - 1, h->metric, 0LL,
+                                                                       h->ws_thr, h->ws_fi);
+        RAG_HIP(hipGetLastError());
+        // 2. filter pass over all rows
+        unsigned int* counts = reinterpret_cast<unsigned int*>(h->ws_cnt);
+        int* nfail = h->ws_cnt + nq;
+        int* failq = h->ws_cnt + nq + 1;
+        RAG_HIP(hipMemsetAsync(h->ws_cnt, 0, (size_t)(nq + 1) * sizeof(int), st));
+        rc = mfma_launch(pf, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
+                         h->zero16, st, nullptr, h->ws_thr, counts);
         if (rc) return rc;
         if (h->prof) {
             RAG_HIP(hipEventRecord(e1, st));
             h->ev_used.emplace_back(e0, e1);
         }
-        merge_fn_t mf = pick_merge(KS, h->metric);
-        mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.nlists, k, D_dev, I_dev, (long long)id_base, k, 0);
+        // 3. exact top-k of each append buffer
+#define RAG_SELECT(KSV)                                                                                             \
+    do {                                                                                                            \
+        if (h->metric == RAG_METRIC_IP)                                                                             \
+            filter_select_kernel<KSV, RAG_METRIC_IP><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(                       \
+                h->ws_key, h->ws_id, counts, cap, k, D_dev, I_dev, (long long)id_base, nfail, failq);               \
+        else                                                                                                        \
+            filter_select_kernel<KSV, RAG_METRIC_L2><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(                       \
+                h->ws_key, h->ws_id, counts, cap, k, D_dev, I_dev, (long long)id_base, nfail, failq);               \
+    } while (0)
+        if (KS == 1) RAG_SELECT(1);
+        else if (KS == 2) RAG_SELECT(2);
+        else RAG_SELECT(4);
+#undef RAG_SELECT
+        RAG_HIP(hipGetLastError());
+        // 4. list-mode redo of the queries that failed (both kernels return at once if none did)
+        rc = mfma_launch(plan, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
+                         h->zero16, st, nfail);
+        if (rc) return rc;
+        mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.nlists, k, D_dev, I_dev, (long long)id_base,
+                                                   k, 0, failq);
         RAG_HIP(hipGetLastError());
         return RAG_OK;
     }
@@ -736,7 +865,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             }
             merge_fn_t mf = pick_merge(KSp, h->metric);
             mf<<<(unsigned)NQ, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, (int)nb, kp, D_dev + q0 * k,
-                                                       I_dev + q0 * k, (long long)id_base, k, done);
+                                                       I_dev + q0 * k, (long long)id_base, k, done, nullptr);
             RAG_HIP(hipGetLastError());
             q0 += NQ;
         }
@@ -782,6 +911,10 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_id);
         (void)hipFree(h->ws_hq);
         (void)hipFree(h->ws_qn);
+        (void)hipFree(h->ws_sD);
+        (void)hipFree(h->ws_sI);
+        (void)hipFree(h->ws_thr);
+        (void)hipFree(h->ws_cnt);
         (void)hipFree(h->zero16);
         (void)hipFree(h->ws_fk);
         (void)hipFree(h->ws_fi);

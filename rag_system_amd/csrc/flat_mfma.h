@@ -11,6 +11,9 @@ struct MfmaPlan {
     int NS;         // LDS-DMA ring stages
     int KS;         // 64-entry register slots per top-k list (1: k <= 64, 2: k <= 128)
     bool bf16;      // rows and queries are bfloat16 (two per 4-byte word)
+    bool filt;      // filter mode: fixed per-query thresholds + append buffers instead of lists
+    int tile_step;  // visit only row tiles t*tile_step (sample pass of the filter mode; else 1)
+    int cap;        // filter mode: entries per query in the append buffer
     int S;          // row splits
     int col_tiles;  // query tiles
     int nlists;     // candidate lists written per query = S * WM
@@ -18,6 +21,10 @@ struct MfmaPlan {
 
 // false if the MFMA path does not serve this shape (k > 128): caller falls back to the scan kernel.
 bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p);
+// Filter-mode plan (no LDS lists, any k): block shape by batch size among the filter-mode shapes.
+bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p);
+// Rows per block tile of a plan (for sizing sample passes).
+int mfma_block_rows(const MfmaPlan& p);
 // out[first + i] = ||X[first + i]||^2 for i in [0, n); ld in elements (fp32 or bfloat16 rows)
 int mfma_row_norms(const void* X, int ld, bool bf16, long long first, long long n, float* out, hipStream_t st);
 // X / Qp are addressed in 4-byte words (ld = words per row; bfloat16: two elements per word).
@@ -25,6 +32,7 @@ int mfma_row_norms(const void* X, int ld, bool bf16, long long first, long long 
 // zero16: >= 16 bytes of zeros in HBM (source of out-of-range K columns / queries).
 int mfma_launch(const MfmaPlan& p, const float* X, long long n, int ld, const float* Qp, int nq, int k, int metric,
                 float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, const float* zero16,
-                hipStream_t st);
+                hipStream_t st, const int* run_flag = nullptr, const float* thr_q = nullptr,
+                unsigned int* counts = nullptr);
 
 }  // namespace rag

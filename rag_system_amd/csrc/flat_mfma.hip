@@ -64,6 +64,9 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     p->NS = NS;
     p->KS = KS;
     p->bf16 = bf16;
+    p->filt = false;
+    p->tile_step = 1;
+    p->cap = 0;
     const int BN = 32 * sh.WN, BM = 32 * sh.MT * sh.WM;
     p->col_tiles = (int)((nq + BN - 1) / BN);
     const long long ntiles = (n + BM - 1) / BM;
@@ -75,6 +78,44 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     p->nlists = p->S * sh.WM;
     return true;
 }
+
+bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p) {
+    if (nq < 1 || n < 1 || cap < 1) return false;
+    int shape = nq > 128 ? 3 : 2;
+    const long long force = options().mfma_shape;
+    if (force == 3 || force == 4 || force == 7 || force == 8) shape = (int)force - 1;
+    int NS = 3;
+    if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
+    const Shape& sh = SHAPES[shape];
+    int bpc = sh.bpc;
+    while (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.BK, NS, 0) * bpc > 160 * 1024) {
+        if (NS > 2) --NS;
+        else if (bpc > 1) --bpc;
+        else return false;
+    }
+    p->shape = shape;
+    p->WM = sh.WM;
+    p->WN = sh.WN;
+    p->MT = sh.MT;
+    p->NS = NS;
+    p->KS = 1;
+    p->bf16 = bf16;
+    p->filt = true;
+    p->tile_step = 1;
+    p->cap = cap;
+    const int BN = 32 * sh.WN, BM = 32 * sh.MT * sh.WM;
+    p->col_tiles = (int)((nq + BN - 1) / BN);
+    const long long ntiles = (n + BM - 1) / BM;
+    long long S = ((long long)num_cus() * bpc + p->col_tiles - 1) / p->col_tiles;
+    if (S >= 8) S = (S + 7) & ~7LL;
+    if (S > ntiles) S = ntiles;
+    if (S < 1) S = 1;
+    p->S = (int)S;
+    p->nlists = 1;
+    return true;
+}
+
+int mfma_block_rows(const MfmaPlan& p) { return 32 * p.MT * p.WM; }
 
 int mfma_row_norms(const void* X, int ld, bool bf16, long long first, long long n, float* out, hipStream_t st) {
     if (n <= 0) return RAG_OK;
@@ -88,8 +129,8 @@ int mfma_row_norms(const void* X, int ld, bool bf16, long long first, long long 
 
 int mfma_launch(const MfmaPlan& p, const float* X, long long n, int ld, const float* Qp, int nq, int k, int metric,
                 float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, const float* zero16,
-                hipStream_t st) {
-    const mfma::Args a{X, n, ld, Qp, nq, k, metric, cand_key, cand_id, xnorm, qnorm, zero16, st};
+                hipStream_t st, const int* run_flag, const float* thr_q, unsigned int* counts) {
+    const mfma::Args a{X, n, ld, Qp, nq, k, metric, cand_key, cand_id, xnorm, qnorm, zero16, st, run_flag, thr_q, counts};
     return p.bf16 ? mfma::dispatch_bf16(p, a) : mfma::dispatch_f32(p, a);
 }
 

@@ -85,11 +85,23 @@ __device__ unsigned long long g_mfma_timing[8];
 #define RAG_TMARK(i)
 #endif
 
-template <int WM, int WN, int MT, int BK, int NS, int KS, int METRIC, bool BF>
+// FILT = false ("list mode"): every (wave, query) keeps an exact sorted k-list in LDS; output
+//   cand[q][s*WM + wm][k].
+// FILT = true ("filter mode", larger k): no lists.  Each query has a fixed threshold thr_q[q]
+//   (the j-th best score of a 1/tile_step sample of the row tiles, found by a list-mode pass);
+//   every row scoring >= it is appended to the query's buffer cand[q][0..cap) through a global
+//   counter.  If k <= count <= cap the top-k of the buffer is the exact global top-k (all rows
+//   >= threshold are in it); otherwise the query is redone in list mode (flat.hip).
+// tile_step: only row tiles t*tile_step are visited (1 = all; the sample pass uses > 1).
+// run_flag: if non-null and *run_flag == 0 the kernel returns at once (the list-mode redo is
+//   enqueued unconditionally and costs a launch when nothing failed).
+template <int WM, int WN, int MT, int BK, int NS, int KS, int METRIC, bool BF, bool FILT>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma_kernel(
     const float* __restrict__ X, long long n, int ld, const float* __restrict__ Qp, int nq, int k, int S,
     int col_tiles, float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
-    const float* __restrict__ qnorm, const float* __restrict__ zero16) {
+    const float* __restrict__ qnorm, const float* __restrict__ zero16, long long tile_step,
+    const int* __restrict__ run_flag, const float* __restrict__ thr_q, unsigned int* __restrict__ counts, int cap) {
+    if (run_flag != nullptr && *run_flag == 0) return;  // uniform, before any barrier
     constexpr int NWV = WM * WN;
     constexpr int T = 64 * NWV;
     constexpr int BMW = 32 * MT;          // rows per wave
@@ -109,9 +121,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
     float* Xs = reinterpret_cast<float*>(smem_raw);                 // [NS][BM][LDS_LD]
     float* Qs = Xs + NS * BM * LDS_LD;                              // [NS][BN][LDS_LD]
     float* dummy = Qs + NS * BN * LDS_LD;                           // [256] sink of filler loads
-    float* lkey = dummy + 256;                                      // [NWV][32][k]
-    int* lid = reinterpret_cast<int*>(lkey + NWV * 32 * k);         // [NWV][32][k]
-    float* scratch = reinterpret_cast<float*>(lid + NWV * 32 * k);  // [NWV][32]
+    const int kl = FILT ? 0 : k;                                    // list entries held in LDS
+    float* lkey = dummy + 256;                                      // [NWV][32][kl]
+    int* lid = reinterpret_cast<int*>(lkey + NWV * 32 * kl);        // [NWV][32][kl]
+    float* scratch = reinterpret_cast<float*>(lid + NWV * 32 * kl); // [NWV][32]
     float* xn_s = scratch + NWV * 32;                               // [BM] row norms (L2 only)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -131,22 +144,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
         }
     }
     const int q0 = c * BN;
-    const long long ntiles = (n + BM - 1) / BM;
+    const long long ntiles = ((n + BM - 1) / BM + tile_step - 1) / tile_step;  // tiles this launch visits
     const long long my_tiles = s < ntiles ? (ntiles - s + S - 1) / S : 0;
+    const long long tile_rows = (long long)BM * tile_step;                     // row distance of visited tiles
     const int nk = (ld + BK - 1) / BK;
     const long long total = my_tiles * nk;
 
     // lists start as pads
-    for (int i = tid; i < NWV * 32 * k; i += T) {
+    for (int i = tid; i < NWV * 32 * kl; i += T) {
         lkey[i] = Lowest<float>::v();
         lid[i] = IdPad<int>::v();
     }
-    float thr = Lowest<float>::v();  // current k-th key of this lane's query (within this wave's rows)
+    const int my_q = q0 + 32 * wn + li;  // this lane's query
+    // list mode: current k-th key of this lane's query (within this wave's rows);
+    // filter mode: the query's fixed threshold (padding queries never pass)
+    float thr = Lowest<float>::v();
+    if (FILT) thr = my_q < nq ? thr_q[my_q] : FLT_MAX;
     float qn = 0.f;
-    if (METRIC == RAG_METRIC_L2) {
-        const int qi = q0 + 32 * wn + li;
-        qn = qi < nq ? qnorm[qi] : 0.f;
-    }
+    if (METRIC == RAG_METRIC_L2) qn = my_q < nq ? qnorm[my_q] : 0.f;
 
     // Direct-to-LDS tile loads.  LDS slot s (16 B) of a tile holds row s/CH, physical chunk s%CH =
     // logical chunk (s%CH) ^ swz(row).  A wave instruction fills 64 consecutive slots;
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
         qoff[it] = (it * NWV + wid < QI && q0 + r < nq) ? (long long)(q0 + r) * ld + qcol[it] : -1;
     }
     long long pf_tiles_left = my_tiles;       // prefetch cursor: tiles not yet fully issued
-    long long pf_row0 = (long long)s * BM;
+    long long pf_row0 = (long long)s * tile_rows;
     int pf_ks = 0;
     auto set_tile_offsets = [&]() {
 #pragma unroll
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
             }
             if (part == LPS - 1 && ++pf_ks == nk) {
                 pf_ks = 0;
-                pf_row0 += (long long)S * BM;
+                pf_row0 += (long long)S * tile_rows;
                 if (--pf_tiles_left > 0) set_tile_offsets();
             }
         } else {
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
 
     int cur = 0;
     int ks = 0;                                // K step within the current row tile
-    long long row0 = (long long)s * BM;        // first row of the current row tile
+    long long row0 = (long long)s * tile_rows; // first row of the current row tile
 #ifdef RAG_MFMA_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -315,45 +330,63 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                     float v = acc[t][r];
                     if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn_s[tile_off + ro]) - qn;
                     key[r] = v;
-                    bool ok = v > thr;
+                    bool ok = FILT ? v >= thr : v > thr;
                     if (partial) ok = ok && (rowbase + ro < n);
                     any = any || ok;
                 }
                 const unsigned long long m = __ballot(any);
-                unsigned qm = (unsigned)(m | (m >> 32));
-                while (qm) {
-                    const int j = __ffs(qm) - 1;
-                    qm &= qm - 1;
-                    float* sc = scratch + wid * 32;
-                    if (li == j) {
+                if (FILT) {
+                    if (m != 0ULL && my_q < nq) {
+                        // rare: append every passing row of this lane's query to its buffer
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[(r & 3) + 8 * (r >> 2) + 4 * lh] = key[r];
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const float cs = sc[li];
-                    const long long crow = rowbase + li;
-                    TK tk;
-                    const int lo = (32 * wid + j) * k;
-#pragma unroll
-                    for (int sl = 0; sl < KS; ++sl) {
-                        const int p = sl * 64 + lane;
-                        tk.key[sl] = p < k ? lkey[lo + p] : Lowest<float>::v();
-                        tk.id[sl] = p < k ? lid[lo + p] : IdPad<int>::v();
-                    }
-                    float thr_k;
-                    int thr_i;
-                    tk.kth(k, thr_k, thr_i);
-                    wave_offer<float, int, KS>(tk, k, thr_k, thr_i, cs, (int)crow, lane < 32 && crow < n, lane);
-#pragma unroll
-                    for (int sl = 0; sl < KS; ++sl) {
-                        const int p = sl * 64 + lane;
-                        if (p < k) {
-                            lkey[lo + p] = tk.key[sl];
-                            lid[lo + p] = tk.id[sl];
+                        for (int r = 0; r < 16; ++r) {
+                            const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (key[r] >= thr && rowbase + ro < n) {
+                                const unsigned int slot = atomicAdd(&counts[my_q], 1u);
+                                if (slot < (unsigned int)cap) {
+                                    const long long o = (long long)my_q * cap + slot;
+                                    cand_key[o] = key[r];
+                                    cand_id[o] = (int)(rowbase + ro);
+                                }
+                            }
                         }
                     }
-                    if (li == j) thr = thr_k;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    unsigned qm = (unsigned)(m | (m >> 32));
+                    while (qm) {
+                        const int j = __ffs(qm) - 1;
+                        qm &= qm - 1;
+                        float* sc = scratch + wid * 32;
+                        if (li == j) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sc[(r & 3) + 8 * (r >> 2) + 4 * lh] = key[r];
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const float cs = sc[li];
+                        const long long crow = rowbase + li;
+                        TK tk;
+                        const int lo = (32 * wid + j) * k;
+#pragma unroll
+                        for (int sl = 0; sl < KS; ++sl) {
+                            const int p = sl * 64 + lane;
+                            tk.key[sl] = p < k ? lkey[lo + p] : Lowest<float>::v();
+                            tk.id[sl] = p < k ? lid[lo + p] : IdPad<int>::v();
+                        }
+                        float thr_k;
+                        int thr_i;
+                        tk.kth(k, thr_k, thr_i);
+                        wave_offer<float, int, KS>(tk, k, thr_k, thr_i, cs, (int)crow, lane < 32 && crow < n, lane);
+#pragma unroll
+                        for (int sl = 0; sl < KS; ++sl) {
+                            const int p = sl * 64 + lane;
+                            if (p < k) {
+                                lkey[lo + p] = tk.key[sl];
+                                lid[lo + p] = tk.id[sl];
+                            }
+                        }
+                        if (li == j) thr = thr_k;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
@@ -363,7 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
         cur = cur + 1 == NS ? 0 : cur + 1;
         if (++ks == nk) {
             ks = 0;
-            row0 += (long long)S * BM;
+            row0 += (long long)S * tile_rows;
         }
     }
     wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
@@ -376,9 +409,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
     }
 #endif
 
-    // ---- write the lists of every real query: cand[q][s*WM + wm][k]
+    // ---- list mode: write the lists of every real query: cand[q][s*WM + wm][k]
     __syncthreads();
-    for (int i = tid; i < NWV * 32 * k; i += T) {
+    for (int i = tid; i < NWV * 32 * kl; i += T) {
         const int w = i / (32 * k), rem = i - w * 32 * k;
         const int j = rem / k, p = rem - j * k;
         const int qi = q0 + 32 * (w % WN) + j;
@@ -405,18 +438,22 @@ struct Args {
     int* cand_id;
     const float *xnorm, *qnorm, *zero16;
     hipStream_t st;
+    const int* run_flag;     // optional: launch is a no-op when *run_flag == 0
+    const float* thr_q;      // filter mode: per-query threshold
+    unsigned int* counts;    // filter mode: per-query append counters (zeroed by the caller)
 };
 
-template <int WM, int WN, int MT, int BK, int NS, int KS, bool BF>
+template <int WM, int WN, int MT, int BK, int NS, int KS, bool BF, bool FILT>
 int launch(const MfmaPlan& p, const Args& a) {
-    const size_t smem = smem_need(WM, WN, MT, BK, NS, a.k);
-    auto fn = a.metric == RAG_METRIC_IP ? flat_mfma_kernel<WM, WN, MT, BK, NS, KS, RAG_METRIC_IP, BF>
-                                        : flat_mfma_kernel<WM, WN, MT, BK, NS, KS, RAG_METRIC_L2, BF>;
+    const size_t smem = smem_need(WM, WN, MT, BK, NS, FILT ? 0 : a.k);
+    auto fn = a.metric == RAG_METRIC_IP ? flat_mfma_kernel<WM, WN, MT, BK, NS, KS, RAG_METRIC_IP, BF, FILT>
+                                        : flat_mfma_kernel<WM, WN, MT, BK, NS, KS, RAG_METRIC_L2, BF, FILT>;
     if (smem > 48 * 1024)
         RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem));
-    fn<<<(unsigned)(p.S * p.col_tiles), 64 * WM * WN, smem, a.st>>>(a.X, a.n, a.ld, a.Qp, a.nq, a.k, p.S, p.col_tiles,
-                                                                   a.cand_key, a.cand_id, a.xnorm, a.qnorm, a.zero16);
+    fn<<<(unsigned)(p.S * p.col_tiles), 64 * WM * WN, smem, a.st>>>(
+        a.X, a.n, a.ld, a.Qp, a.nq, a.k, p.S, p.col_tiles, a.cand_key, a.cand_id, a.xnorm, a.qnorm, a.zero16,
+        (long long)p.tile_step, a.run_flag, a.thr_q, a.counts, p.cap);
     RAG_HIP(hipGetLastError());
     return RAG_OK;
 }
@@ -438,22 +475,33 @@ constexpr Shape SHAPES[] = {
 constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
 // One translation unit per element type instantiates its kernels behind this dispatcher
-// (flat_mfma_f32.hip / flat_mfma_bf16.hip).  KS = 2 (64 < k <= 128) exists for the 4-wave
-// shapes only: eight waves' lists of that length do not fit the LDS.
+// (flat_mfma_f32.hip / flat_mfma_bf16.hip).  List mode: KS = 2 (64 < k <= 128) exists for the
+// 4-wave shapes only (eight waves' lists of that length do not fit the LDS).  Filter mode holds
+// no lists and is built for the (1,4,8) and (1,8,8) shapes.
 template <bool BF>
 int dispatch(const MfmaPlan& p, const Args& a) {
-#define RAG_MFMA_NS(WM, WN, MT, BK, KS) \
-    (p.NS >= 3 ? launch<WM, WN, MT, BK, 3, KS, BF>(p, a) : launch<WM, WN, MT, BK, 2, KS, BF>(p, a))
-#define RAG_MFMA_4W(WM, WN, MT, BK) (p.KS == 2 ? RAG_MFMA_NS(WM, WN, MT, BK, 2) : RAG_MFMA_NS(WM, WN, MT, BK, 1))
+#define RAG_MFMA_NS(WM, WN, MT, BK, KS, FILT) \
+    (p.NS >= 3 ? launch<WM, WN, MT, BK, 3, KS, BF, FILT>(p, a) : launch<WM, WN, MT, BK, 2, KS, BF, FILT>(p, a))
+#define RAG_MFMA_4W(WM, WN, MT, BK) \
+    (p.KS == 2 ? RAG_MFMA_NS(WM, WN, MT, BK, 2, false) : RAG_MFMA_NS(WM, WN, MT, BK, 1, false))
+    if (p.filt) {
+        switch (p.shape) {
+            case 2: return RAG_MFMA_NS(1, 4, 8, 16, 1, true);
+            case 3: return RAG_MFMA_NS(1, 8, 8, 16, 1, true);
+            case 6: return RAG_MFMA_NS(1, 4, 8, 32, 1, true);
+            case 7: return RAG_MFMA_NS(1, 8, 8, 32, 1, true);
+            default: return fail(RAG_ERR_INVALID_ARG, "no filter-mode kernel for block shape %d", p.shape + 1);
+        }
+    }
     switch (p.shape) {
         case 0: return RAG_MFMA_4W(4, 1, 2, 16);
         case 1: return RAG_MFMA_4W(2, 2, 4, 16);
         case 2: return RAG_MFMA_4W(1, 4, 8, 16);
-        case 3: return RAG_MFMA_NS(1, 8, 8, 16, 1);
+        case 3: return RAG_MFMA_NS(1, 8, 8, 16, 1, false);
         case 4: return RAG_MFMA_4W(4, 1, 2, 32);
         case 5: return RAG_MFMA_4W(2, 2, 4, 32);
         case 6: return RAG_MFMA_4W(1, 4, 8, 32);
-        default: return RAG_MFMA_NS(1, 8, 8, 32, 1);
+        default: return RAG_MFMA_NS(1, 8, 8, 32, 1, false);
     }
 #undef RAG_MFMA_4W
 #undef RAG_MFMA_NS

@@ -90,6 +90,8 @@ int rag_set_option(const char* name, int64_t value) {
     else if (!std::strcmp(name, "mfma_shape")) o.mfma_shape = value;
     else if (!std::strcmp(name, "mfma_bpc")) o.mfma_bpc = value;
     else if (!std::strcmp(name, "mfma_stages")) o.mfma_stages = value;
+    else if (!std::strcmp(name, "mfma_filter_k")) o.mfma_filter_k = value;
+    else if (!std::strcmp(name, "mfma_filter_min_rows")) o.mfma_filter_min_rows = value;
     else return rag::fail(RAG_ERR_INVALID_ARG, "unknown option '%s'", name);
     return RAG_OK;
 }

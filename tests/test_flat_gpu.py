@@ -349,3 +349,81 @@ def test_every_mfma_block_shape_and_ring_depth(engine):
     finally:
         lib.rag_set_option(b"mfma_shape", 0)
         lib.rag_set_option(b"mfma_stages", 0)
+
+
+def _with_options(lib, opts):
+    from rag_system_amd import _lib
+    for name, val in opts.items():
+        _lib.check(lib.rag_set_option(name.encode(), val))
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_mfma_filter_mode_matches_oracle(engine, storage):
+    """Filter mode of the batch kernel (sample pass -> thresholds -> append -> select, with the
+    list-mode redo for queries whose count falls outside [k, cap]) forced on small inputs."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(4242)
+    rnd = od.bf16_round if storage == "bf16" else (lambda a: a)
+    try:
+        _with_options(lib, {"mfma_filter_k": 1, "mfma_filter_min_rows": 1})
+        for metric in (0, 1):
+            for n, d in [(300, 64), (20_011, 384), (70_001, 72)]:
+                X = _rand_unit(rng, n, d)
+                X[n // 2] = X[3]
+                X[n - 1] = X[3]
+                idx = faiss.IndexFlat(d, metric, storage=storage)
+                idx.add(X)
+                Xr = rnd(X)
+                for nq, k in [(5, 10), (33, 1), (64, 100), (130, 50), (300, 128)]:
+                    Q = _rand_unit(rng, nq, d)
+                    Q[0] = X[3]
+                    Qr = rnd(Q)
+                    D, I = idx.search(Q, k)
+                    _, Ir, D64 = od.flat_search(Xr, Qr, k, metric)
+                    od.check_topk(D, I, D64, Ir, RTOL, ATOL if metric == 0 else 4e-6, _scorer(Xr, Qr, metric))
+        # adversarial row orders for the 1-in-32 tile sample (row tiles of 256 rows)
+        n, d, k = 40_000, 32, 20
+        Q = _rand_unit(rng, 12, d)
+        base = _rand_unit(rng, n, d) * 0.01
+        tile = np.arange(n) // 256
+        cases = {}
+        a = base.copy(); a[:] = a[0]                                  # every score equal: overflow -> redo
+        cases["all_equal"] = a
+        b = base.copy(); b[(tile % 32 == 0)] *= 100.0                 # the best rows are all in sampled tiles: count < k... or exact
+        cases["best_in_sample"] = b
+        c = base.copy(); c[(tile % 32 == 5)] *= 100.0                 # the best rows are never sampled: huge counts
+        cases["best_outside_sample"] = c
+        e = base.copy(); e[:300] = Q[0] * 3.0                         # 300 exact ties at the top for query 0
+        cases["ties_at_top"] = e
+        for name, X in cases.items():
+            idx = faiss.IndexFlat(d, 0, storage=storage)
+            idx.add(X)
+            Xr, Qr = rnd(X), rnd(Q)
+            D, I = idx.search(Q, k)
+            _, Ir, D64 = od.flat_search(Xr, Qr, k, 0)
+            od.check_topk(D, I, D64, Ir, RTOL, ATOL, _scorer(Xr, Qr, 0))
+            if name in ("all_equal", "ties_at_top"):
+                assert np.array_equal(I[0], Ir[0]), name          # exact ties: lower id first
+    finally:
+        _with_options(lib, {"mfma_filter_k": 33, "mfma_filter_min_rows": 1 << 19})
+
+
+def test_mfma_filter_mode_default_thresholds(engine):
+    """600k x 64 rows, k = 50: filter mode by default; identical ids to list mode."""
+    from rag_system_amd import _lib
+    lib = _lib.engine()
+    rng = np.random.default_rng(99)
+    X = _rand_unit(rng, 600_000, 64)
+    Q = _rand_unit(rng, 40, 64)
+    idx = _index(64)
+    idx.add(X)
+    D, I = idx.search(Q, 50)
+    _, Ir, D64 = od.flat_search(X, Q, 50, 0)
+    od.check_topk(D, I, D64, Ir, RTOL, ATOL, _scorer(X, Q, 0))
+    try:
+        _with_options(lib, {"mfma_filter_k": 1000})
+        D2, I2 = idx.search(Q, 50)
+    finally:
+        _with_options(lib, {"mfma_filter_k": 33})
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
