@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from rag_system_amd import _lib, faiss_compat as faiss  # noqa: E402
 
-DEFAULTS = {"scan_blocks": 0, "scan_nt": 1, "scan_rows": 0, "mfma_min_nq": 5, "mfma_shape": 0, "mfma_bpc": 0, "mfma_stages": 0}
+DEFAULTS = {"scan_blocks": 0, "scan_nt": 1, "scan_rows": 0, "mfma_min_nq": 0, "mfma_shape": 0, "mfma_bpc": 0, "mfma_stages": 0}
 
 
 def main():

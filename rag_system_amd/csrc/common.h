@@ -23,7 +23,7 @@ struct Options {
     int64_t scan_blocks = 0;   // 0 = auto (CUs * blocks_per_cu)
     int64_t scan_nt = 1;       // non-temporal loads for the streamed matrix
     int64_t scan_rows = 0;     // rows per wave tile (0 = auto)
-    int64_t mfma_min_nq = 5;   // nq >= this -> MFMA batch kernel
+    int64_t mfma_min_nq = 0;   // nq >= this -> MFMA batch kernel (0 = auto: 3 for fp32 rows, 2 for bfloat16)
     int64_t mfma_shape = 0;    // force MFMA block shape 1..8 (0 = by batch size)
     int64_t mfma_stages = 0;   // force LDS ring depth 2..3 (0 = auto)
     int64_t mfma_bpc = 0;      // force MFMA blocks per CU used to size the row split (0 = auto)

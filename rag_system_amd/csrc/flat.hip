@@ -9,7 +9,7 @@
 // are exact in fp32 and accumulation is fp32, so the scores are those of the rounded
 // operands to fp32 accuracy whatever the batch size.
 //
-// Small query batches (nq <= 4 per pass): flat_scan_kernel -- a bandwidth-bound fused GEMV.
+// Small query batches (nq <= 2 per pass): flat_scan_kernel -- a bandwidth-bound fused GEMV.
 //   * every wave streams tiles of R consecutive rows with 16-byte coalesced loads
 //     (lane l reads float4 l, l+64, ... of the row: 1 KiB contiguous per wave instruction),
 //   * the query sits in LDS, partial dot products stay in registers,
@@ -615,8 +615,7 @@ scan_fn_t pick_scan(const ScanCfg& c) {
         if (c.R == 8) return pick_scan1<8, 1>(c.KS, c.metric, c.nt, c.bf);
         return pick_scan1<4, 1>(c.KS, c.metric, c.nt, c.bf);
     }
-    if (c.NQ == 2) return pick_scan1<4, 2>(c.KS, c.metric, c.nt, c.bf);
-    return pick_scan1<4, 4>(c.KS, c.metric, c.nt, c.bf);
+    return pick_scan1<4, 2>(c.KS, c.metric, c.nt, c.bf);
 }
 
 typedef void (*merge_fn_t)(const float*, const int*, int, int, float*, long long*, long long, int, int, const int*);
@@ -666,7 +665,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     }
 
     MfmaPlan plan;
-    if (nq >= opt.mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan)) {
+    // batches from 3 queries (fp32 rows; 2 for bfloat16 rows) take the MFMA kernel: measured on
+    // 10M rows, fp32 nq=2 scan 2.35 ms vs MFMA 3.1 ms, nq=3 4.6 vs 3.2; bf16 nq=2 2.61 vs 2.54
+    const int64_t mfma_min_nq = opt.mfma_min_nq > 0 ? opt.mfma_min_nq : (bf ? 2 : 3);
+    if (nq >= mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan)) {
         // Filter mode for larger k on large shards: a 1/FILTER_STEP sample of the row tiles gives
         // each query a threshold (its j-th best sample score), one pass appends every row at or
         // above it, and the top-k of the few hundred appended rows is the exact result.  With
@@ -824,7 +826,9 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         }
         for (int64_t q0 = 0; q0 < nq;) {
             const int64_t left = nq - q0;
-            const int NQ = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+            // pairs at most: a 4-query tile (16 partial sums per wave reduction) measured 2.9x the
+            // time of a pair (10M x 384: 6.8 ms vs 2.35 ms)
+            const int NQ = left >= 2 ? 2 : 1;
             const int R = NQ == 1 ? Rsel : 4;
             const int64_t ntiles = (n + R - 1) / R;
             int64_t nb = std::min<int64_t>(blocks, (ntiles + SCAN_WAVES - 1) / SCAN_WAVES);

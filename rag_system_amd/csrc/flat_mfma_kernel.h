@@ -272,6 +272,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
             const int sw = swz<BK>(li);  // = swz(row): every tile starts at a multiple of 32 rows
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
+                // The next stage's loads go out behind the first MFMA batches: the waves of a CU
+                // share one address path (64 B/clk), and a wave that queues there with nothing in
+                // the matrix pipe leaves its SIMD idle.  Measured slower and dropped: spreading
+                // the loads one by one between MFMAs with double-buffered fragments (+32 VGPRs
+                // spill the 8-wave shapes); letting the two waves of a SIMD queue at different
+                // points of the K step.
+                if (kk == BK / 16) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    RAG_TMARK(2)
+                    int nxt = cur + NS - 1;
+                    nxt = nxt >= NS ? nxt - NS : nxt;
+                    issue_loads(nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const int pc = ((kk * 2 + lh) ^ sw) * 4;
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(qs + (32 * wn + li) * LDS_LD + pc);
                 f32x4 a[MT];
@@ -290,19 +304,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
 #pragma unroll
                         for (int t = 0; t < MT; ++t)
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][cc], bq[cc], acc[t], 0, 0, 0);
-                }
-                if (kk == 0) {
-                    // The next stage's loads go out behind the first batch of MFMAs: the waves of
-                    // a CU share one address path (64 B/clk), and a wave that queues there with
-                    // nothing in the matrix pipe leaves its SIMD idle.  (Spreading the loads one
-                    // by one between MFMAs and double-buffering the fragments was measured
-                    // slower: +32 VGPRs spill the 8-wave shapes.)
-                    __builtin_amdgcn_sched_barrier(0);
-                    RAG_TMARK(2)
-                    int nxt = cur + NS - 1;
-                    nxt = nxt >= NS ? nxt - NS : nxt;
-                    issue_loads(nxt);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
