@@ -47,6 +47,55 @@ __device__ __forceinline__ double shift_up1(double v) {
     return __longlong_as_double(shift_up1(__double_as_longlong(v)));
 }
 
+// lane i takes the value of lane i^D without the LDS crossbar: quad_perm DPP (D = 1, 2), a pair
+// of bank-masked row shifts (D = 4, 8), v_permlane16_swap / v_permlane32_swap (gfx950) + select.
+// Checked on the device by benchmarks/xor_lane_check.hip.
+template <int D>
+__device__ __forceinline__ int xor_lane(int v) {
+    static_assert(D == 1 || D == 2 || D == 4 || D == 8 || D == 16 || D == 32, "lane distance");
+    if constexpr (D == 1) {
+        return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);   // quad_perm:[1,0,3,2]
+    } else if constexpr (D == 2) {
+        return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+    } else if constexpr (D == 4) {
+        const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);  // row_shl:4 -> banks 0,2
+        return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xF, 0xA, false);         // row_shr:4 -> banks 1,3
+    } else if constexpr (D == 8) {
+        const int r = __builtin_amdgcn_update_dpp(v, v, 0x108, 0xF, 0x3, false);  // row_shl:8 -> banks 0,1
+        return __builtin_amdgcn_update_dpp(r, v, 0x118, 0xF, 0xC, false);         // row_shr:8 -> banks 2,3
+    } else if constexpr (D == 16) {
+        const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (threadIdx.x & 16) ? p[0] : p[1];
+    } else {
+        const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? p[0] : p[1];
+    }
+}
+template <int D> __device__ __forceinline__ unsigned int xor_lane(unsigned int v) { return (unsigned int)xor_lane<D>((int)v); }
+template <int D> __device__ __forceinline__ float xor_lane(float v) { return __int_as_float(xor_lane<D>(__float_as_int(v))); }
+template <int D> __device__ __forceinline__ long long xor_lane(long long v) {
+    const int lo = xor_lane<D>((int)(v & 0xFFFFFFFFLL));
+    const int hi = xor_lane<D>((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+template <int D> __device__ __forceinline__ double xor_lane(double v) {
+    return __longlong_as_double(xor_lane<D>(__double_as_longlong(v)));
+}
+// lane i takes the value of lane 63-i: row_mirror DPP (reverse within 16) + the two swaps
+__device__ __forceinline__ int reverse_lanes(int v) {
+    const int r = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);
+    return xor_lane<32>(xor_lane<16>(r));
+}
+__device__ __forceinline__ float reverse_lanes(float v) { return __int_as_float(reverse_lanes(__float_as_int(v))); }
+__device__ __forceinline__ long long reverse_lanes(long long v) {
+    const int lo = reverse_lanes((int)(v & 0xFFFFFFFFLL));
+    const int hi = reverse_lanes((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ double reverse_lanes(double v) {
+    return __longlong_as_double(reverse_lanes(__double_as_longlong(v)));
+}
+
 template <typename KeyT, typename IdT, int KS>
 struct WaveTopK {
     KeyT key[KS];
@@ -123,25 +172,136 @@ __device__ __forceinline__ void wave_offer(WaveTopK<KeyT, IdT, KS>& tk, int k, K
     }
 }
 
+// ---- batch updates: bitonic sort / merge of 64*KS (key, id) pairs held one per (slot, lane) ----
+// Element index e = slot*64 + lane.  A sorted insert costs ~0.3 us (a chain of ~80 dependent
+// instructions); when more than a handful of candidates of a 64*KS chunk beat the threshold it is
+// cheaper to sort the chunk (log^2 steps) and merge it with the list (log steps) at once.
+template <typename KeyT, typename IdT, int KS>
+struct WaveBitonic {
+    using TK = WaveTopK<KeyT, IdT, KS>;
+    static constexpr int N = 64 * KS;
+
+    // one compare-exchange step at distance D inside blocks of SZ (SZ >= N: whole array best-first)
+    template <int D, int SZ>
+    static __device__ __forceinline__ void step(KeyT (&key)[KS], IdT (&id)[KS], int lane) {
+        if constexpr (D >= 64) {
+            constexpr int DS = D >> 6;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ps = s ^ DS;
+                if (ps > s) {  // s is the lower index of the pair
+                    const bool dir = SZ >= N ? true : (((s * 64) & SZ) == 0);
+                    const bool swap = dir ? TK::ahead(key[ps], id[ps], key[s], id[s])
+                                          : TK::ahead(key[s], id[s], key[ps], id[ps]);
+                    if (swap) {
+                        const KeyT tk_ = key[s]; key[s] = key[ps]; key[ps] = tk_;
+                        const IdT ti_ = id[s]; id[s] = id[ps]; id[ps] = ti_;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const KeyT ok = xor_lane<D>(key[s]);
+                const IdT oi = xor_lane<D>(id[s]);
+                const int e = s * 64 + lane;
+                const bool lower = (lane & D) == 0;
+                const bool dir = SZ >= N ? true : ((e & SZ) == 0);
+                const bool keep_better = lower == dir;
+                const bool take = keep_better ? TK::ahead(ok, oi, key[s], id[s]) : TK::ahead(key[s], id[s], ok, oi);
+                if (take) {
+                    key[s] = ok;
+                    id[s] = oi;
+                }
+            }
+        }
+    }
+    template <int D, int SZ>
+    static __device__ __forceinline__ void steps_down(KeyT (&key)[KS], IdT (&id)[KS], int lane) {
+        step<D, SZ>(key, id, lane);
+        if constexpr (D > 1) steps_down<D / 2, SZ>(key, id, lane);
+    }
+    template <int SZ>
+    static __device__ __forceinline__ void sort_from(KeyT (&key)[KS], IdT (&id)[KS], int lane) {
+        steps_down<SZ / 2, SZ>(key, id, lane);
+        if constexpr (SZ < N) sort_from<SZ * 2>(key, id, lane);
+    }
+    // full bitonic sort, best first
+    static __device__ __forceinline__ void sort(KeyT (&key)[KS], IdT (&id)[KS], int lane) { sort_from<2>(key, id, lane); }
+
+    // list (sorted best-first) <- best N of list U chunk (sorted best-first), sorted best-first
+    static __device__ __forceinline__ void merge(TK& tk, const KeyT (&ck)[KS], const IdT (&ci)[KS], int lane) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {  // against the reversed chunk: the result is bitonic
+            const KeyT rk = reverse_lanes(ck[KS - 1 - s]);
+            const IdT ri = reverse_lanes(ci[KS - 1 - s]);
+            if (TK::ahead(rk, ri, tk.key[s], tk.id[s])) {
+                tk.key[s] = rk;
+                tk.id[s] = ri;
+            }
+        }
+        steps_down<N / 2, N>(tk.key, tk.id, lane);
+    }
+};
+
+// Offer a chunk of 64*KS candidates (one per slot and lane).  Few beat the threshold: sorted
+// inserts.  Many: filter, sort (unless `sorted`: the chunk is already best-first with pads last)
+// and merge.  The result is the same list either way (the order is total).
+template <typename KeyT, typename IdT, int KS>
+__device__ __forceinline__ void wave_offer_chunk(WaveTopK<KeyT, IdT, KS>& tk, int k, KeyT& thr_k, IdT& thr_i,
+                                                 KeyT (&ck)[KS], IdT (&ci)[KS], const bool (&valid)[KS], bool sorted,
+                                                 int lane) {
+    using TK = WaveTopK<KeyT, IdT, KS>;
+    bool acc[KS];
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        acc[s] = valid[s] && TK::ahead(ck[s], ci[s], thr_k, thr_i);
+        cnt += __popcll(__ballot(acc[s]));
+    }
+    if (cnt == 0) return;
+    // measured on one wave (benchmarks/topk_cost.hip): insert 310/500/960 cycles (KS 1/2/4), sort
+    // 6.6k/17.7k/44k, merge 2.0k/4.2k/8.6k: sorting pays from ~28/44/55 accepted candidates, a
+    // merge alone from ~7/9/9
+    if (cnt <= (sorted ? 8 : 24 + 10 * KS)) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wave_offer<KeyT, IdT, KS>(tk, k, thr_k, thr_i, ck[s], ci[s], acc[s], lane);
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        if (!acc[s]) {
+            ck[s] = Lowest<KeyT>::v();
+            ci[s] = IdPad<IdT>::v();
+        }
+    if (!sorted) WaveBitonic<KeyT, IdT, KS>::sort(ck, ci, lane);
+    WaveBitonic<KeyT, IdT, KS>::merge(tk, ck, ci, lane);
+    tk.kth(k, thr_k, thr_i);
+}
+
 // Sum N = 2^LOGN per-lane values across the wave at once.  Returns, in every lane, the
 // wave-wide total of item (lane >> (6-LOGN)); costs N-1 select/shuffle/add steps plus
 // 6-LOGN plain butterfly steps instead of 6*N.  Summation order is fixed (deterministic).
+template <int N, int HALF, int DIST>
+__device__ __forceinline__ void wave_multi_reduce_fold(float (&v)[N], int lane) {
+    if constexpr (HALF >= 1) {
+        const bool upper = (lane & DIST) != 0;
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const float keep = upper ? v[i + HALF] : v[i];
+            const float send = upper ? v[i] : v[i + HALF];
+            v[i] = keep + xor_lane<DIST>(send);
+        }
+        wave_multi_reduce_fold<N, HALF / 2, DIST / 2>(v, lane);
+    } else if constexpr (DIST >= 1) {
+        v[0] += xor_lane<DIST>(v[0]);
+        wave_multi_reduce_fold<N, 0, DIST / 2>(v, lane);
+    }
+}
 template <int N>
 __device__ __forceinline__ float wave_multi_reduce(float (&v)[N], int lane) {
     static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two <= 64");
-    int dist = 32;
-#pragma unroll
-    for (int half = N / 2; half >= 1; half >>= 1) {
-        const bool upper = (lane & dist) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float keep = upper ? v[i + half] : v[i];
-            const float send = upper ? v[i] : v[i + half];
-            v[i] = keep + __shfl_xor(send, dist);
-        }
-        dist >>= 1;
-    }
-    for (; dist >= 1; dist >>= 1) v[0] += __shfl_xor(v[0], dist);
+    wave_multi_reduce_fold<N, N / 2, 32>(v, lane);
     return v[0];
 }
 
@@ -182,6 +342,7 @@ __device__ __forceinline__ void block_merge(Loader load, long long C, int k, Wav
     // U independent candidate loads are in flight before the first is offered: one round trip to
     // memory per U*64 candidates instead of one per 64 (the loop is latency-bound otherwise).
     constexpr int U = 8;
+    static_assert(U % KS == 0, "chunks of KS groups");
     for (long long base = (long long)wid * 64 * U; base < C; base += (long long)NWAVES * 64 * U) {
         KeyT ck[U];
         IdT ci[U];
@@ -194,7 +355,18 @@ __device__ __forceinline__ void block_merge(Loader load, long long C, int k, Wav
             valid[u] = c < C ? load(c, ck[u], ci[u]) : false;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) wave_offer<KeyT, IdT, KS>(tk, k, thr_k, thr_i, ck[u], ci[u], valid[u], lane);
+        for (int u = 0; u < U; u += KS) {
+            KeyT k2[KS];
+            IdT i2[KS];
+            bool v2[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                k2[s] = ck[u + s];
+                i2[s] = ci[u + s];
+                v2[s] = valid[u + s];
+            }
+            wave_offer_chunk<KeyT, IdT, KS>(tk, k, thr_k, thr_i, k2, i2, v2, false, lane);
+        }
     }
     if (wid > 0) {
 #pragma unroll
@@ -206,12 +378,19 @@ __device__ __forceinline__ void block_merge(Loader load, long long C, int k, Wav
     }
     __syncthreads();
     if (wid == 0) {
-        for (int w = 0; w < NWAVES - 1; ++w)
+        for (int w = 0; w < NWAVES - 1; ++w) {  // the other waves' lists are sorted: merge only
+            KeyT k2[KS];
+            IdT i2[KS];
+            bool v2[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int o = (w * KS + s) * 64 + lane;
-                wave_offer<KeyT, IdT, KS>(tk, k, thr_k, thr_i, mk[o], mi[o], true, lane);
+                k2[s] = mk[o];
+                i2[s] = mi[o];
+                v2[s] = true;
             }
+            wave_offer_chunk<KeyT, IdT, KS>(tk, k, thr_k, thr_i, k2, i2, v2, true, lane);
+        }
     }
 }
 
