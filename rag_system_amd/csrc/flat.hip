@@ -227,24 +227,29 @@ __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
     __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
     const long long q = blockIdx.x;
     if (only_if != nullptr && only_if[q] == 0) return;  // redo pass: only the queries that failed
-    const long long C = (long long)nlists * k;
-    const float* ck = cand_key + q * C;
-    const int* ci = cand_id + q * C;
-    __shared__ float red[MERGE_WAVES];
-    const float floor_key = block_max_kth<float, MERGE_WAVES>(
-        [&](int l) {
-            const long long o = (long long)l * k + (k - 1);
-            return ci[o] != IdPad<int>::v() ? ck[o] : Lowest<float>::v();
-        },
-        nlists, red);
+    const float* ck = cand_key + q * (long long)nlists * k;
+    const int* ci = cand_id + q * (long long)nlists * k;
     WaveTopK<float, int, KS> tk;
-    block_merge<float, int, KS, MERGE_WAVES>(
-        [&](long long c, float& key, int& id) {
-            key = ck[c];
-            id = ci[c];
-            return id != IdPad<int>::v() && key >= floor_key;
-        },
-        C, k, tk, mk, mi);
+    if (KS == 1 && k <= 32) {
+        // short lists: several lists share a 64-candidate chunk (flat walk, sorted inserts)
+        block_merge<float, int, KS, MERGE_WAVES>(
+            [&](long long c, float& key, int& id) {
+                key = ck[c];
+                id = ci[c];
+                return id != IdPad<int>::v();
+            },
+            (long long)nlists * k, k, tk, mk, mi);
+    } else {
+        // a whole sorted list per chunk: bitonic merge or a few inserts, never a sort
+        block_merge_lists<float, int, KS, MERGE_WAVES>(
+            [&](int l, int p, float& key, int& id) {
+                const long long o = (long long)l * k + p;
+                key = ck[o];
+                id = ci[o];
+                return id != IdPad<int>::v();
+            },
+            nlists, k, tk, mk, mi);
+    }
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
 #pragma unroll
@@ -269,26 +274,30 @@ __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
     __shared__ float mk[(MERGE_WAVES - 1) * KS * 64];
     __shared__ long long mi[(MERGE_WAVES - 1) * KS * 64];
     const long long q = blockIdx.x;
-    const long long C = (long long)nlists * k;
     const bool ip = metric == RAG_METRIC_IP;
-    __shared__ float red[MERGE_WAVES];
-    const float floor_key = block_max_kth<float, MERGE_WAVES>(
-        [&](int l) {
-            const long long o = ((long long)l * nq + q) * k + (k - 1);
-            return Il[o] >= 0 ? (ip ? Dl[o] : -Dl[o]) : Lowest<float>::v();
-        },
-        nlists, red);
     WaveTopK<float, long long, KS> tk;
-    block_merge<float, long long, KS, MERGE_WAVES>(
-        [&](long long c, float& key, long long& id) {
-            const long long l = c / k, j = c - l * k;
-            const long long o = (l * nq + q) * k + j;
-            id = Il[o];
-            const float v = Dl[o];
-            key = ip ? v : -v;
-            return id >= 0 && key >= floor_key;
-        },
-        C, k, tk, mk, mi);
+    if (KS == 1 && k <= 32) {
+        block_merge<float, long long, KS, MERGE_WAVES>(
+            [&](long long c, float& key, long long& id) {
+                const long long l = c / k, j = c - l * k;
+                const long long o = (l * nq + q) * k + j;
+                id = Il[o];
+                const float v = Dl[o];
+                key = ip ? v : -v;
+                return id >= 0;
+            },
+            (long long)nlists * k, k, tk, mk, mi);
+    } else {
+        block_merge_lists<float, long long, KS, MERGE_WAVES>(
+            [&](int l, int p, float& key, long long& id) {
+                const long long o = ((long long)l * nq + q) * k + p;
+                id = Il[o];
+                const float v = Dl[o];
+                key = ip ? v : -v;
+                return id >= 0;
+            },
+            nlists, k, tk, mk, mi);
+    }
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
 #pragma unroll

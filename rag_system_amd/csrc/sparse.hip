@@ -99,22 +99,25 @@ __global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const d
                                                                          long long* __restrict__ I) {
     __shared__ double mk[(MERGE_WAVES - 1) * KS * 64];
     __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
-    const long long C = (long long)nlists * k;
-    __shared__ double red[MERGE_WAVES];
-    const double floor_key = block_max_kth<double, MERGE_WAVES>(
-        [&](int l) {
-            const long long o = (long long)l * k + (k - 1);
-            return cand_id[o] != IdPad<int>::v() ? cand_key[o] : Lowest<double>::v();
-        },
-        nlists, red);
     WaveTopK<double, int, KS> tk;
-    block_merge<double, int, KS, MERGE_WAVES>(
-        [&](long long c, double& key, int& id) {
-            key = cand_key[c];
-            id = cand_id[c];
-            return id != IdPad<int>::v() && key >= floor_key;
-        },
-        C, k, tk, mk, mi);
+    if (KS == 1 && k <= 32) {
+        block_merge<double, int, KS, MERGE_WAVES>(
+            [&](long long c, double& key, int& id) {
+                key = cand_key[c];
+                id = cand_id[c];
+                return id != IdPad<int>::v();
+            },
+            (long long)nlists * k, k, tk, mk, mi);
+    } else {
+        block_merge_lists<double, int, KS, MERGE_WAVES>(
+            [&](int l, int p, double& key, int& id) {
+                const long long o = (long long)l * k + p;
+                key = cand_key[o];
+                id = cand_id[o];
+                return id != IdPad<int>::v();
+            },
+            nlists, k, tk, mk, mi);
+    }
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
 #pragma unroll

@@ -394,6 +394,64 @@ __device__ __forceinline__ void block_merge(Loader load, long long C, int k, Wav
     }
 }
 
+// Block-wide merge of `nlists` SORTED k-lists (best first, pads last) into one sorted k-list held
+// by wave 0.  `load(l, p, key, id)` returns the validity of entry p of list l.  A whole list is one
+// chunk (entry p in slot p/64, lane p%64), already sorted: it is merged by the bitonic network, or
+// by a few sorted inserts when only a few of its entries beat the wave's threshold -- no sort and
+// no per-candidate insert chain as in block_merge.  U lists are in flight per wave.
+template <typename KeyT, typename IdT, int KS, int NWAVES, class Loader>
+__device__ __forceinline__ void block_merge_lists(Loader load, int nlists, int k, WaveTopK<KeyT, IdT, KS>& tk,
+                                                  KeyT* mk, IdT* mi) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    KeyT thr_k = Lowest<KeyT>::v();
+    IdT thr_i = IdPad<IdT>::v();
+    tk.init();
+    constexpr int U = 4;
+    for (int l0 = wid; l0 < nlists; l0 += NWAVES * U) {
+        KeyT ck[U][KS];
+        IdT ci[U][KS];
+        bool valid[U][KS];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = l0 + u * NWAVES;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s * 64 + lane;
+                ck[u][s] = Lowest<KeyT>::v();
+                ci[u][s] = IdPad<IdT>::v();
+                valid[u][s] = (l < nlists && p < k) ? load(l, p, ck[u][s], ci[u][s]) : false;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            wave_offer_chunk<KeyT, IdT, KS>(tk, k, thr_k, thr_i, ck[u], ci[u], valid[u], true, lane);
+    }
+    if (wid > 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int o = ((wid - 1) * KS + s) * 64 + lane;
+            mk[o] = tk.key[s];
+            mi[o] = tk.id[s];
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+        for (int w = 0; w < NWAVES - 1; ++w) {
+            KeyT k2[KS];
+            IdT i2[KS];
+            bool v2[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int o = (w * KS + s) * 64 + lane;
+                k2[s] = mk[o];
+                i2[s] = mi[o];
+                v2[s] = true;
+            }
+            wave_offer_chunk<KeyT, IdT, KS>(tk, k, thr_k, thr_i, k2, i2, v2, true, lane);
+        }
+    }
+}
+
 template <int N> struct Log2 { static constexpr int v = 1 + Log2<N / 2>::v; };
 template <> struct Log2<1> { static constexpr int v = 0; };
 
