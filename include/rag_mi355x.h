@@ -113,6 +113,12 @@ int rag_flat_copy_to_host(rag_flat_t* h, int64_t first, int64_t n, float* out);
 int rag_topk_merge_dev(int metric, int nlists, int64_t nq, int k,
                        const float* D_lists_dev, const int64_t* I_lists_dev,
                        float* D_dev, int64_t* I_dev, void* stream);
+/* Same merge with the lists `stride_D` floats / `stride_I` int64 apart (>= nq*k): lets the
+ * per-rank scores and ids travel in ONE packed all-gather buffer (rag_system_amd/sharded.py). */
+int rag_topk_merge_strided_dev(int metric, int nlists, int64_t nq, int k,
+                               const float* D_lists_dev, const int64_t* I_lists_dev,
+                               int64_t stride_D, int64_t stride_I,
+                               float* D_dev, int64_t* I_dev, void* stream);
 /* Kernel-time accounting for the dense scan kernel (the dominant kernel):
  * when enabled, every search brackets the scan kernel with HIP events on the
  * stream it is launched on. */

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
 template <int KS>
 __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
     int metric, const float* __restrict__ Dl, const long long* __restrict__ Il, int nlists, long long nq,
-    int k, float* __restrict__ D, long long* __restrict__ I) {
+    int k, float* __restrict__ D, long long* __restrict__ I, long long stride_D, long long stride_I) {
     __shared__ float mk[(MERGE_WAVES - 1) * KS * 64];
     __shared__ long long mi[(MERGE_WAVES - 1) * KS * 64];
     const long long q = blockIdx.x;
@@ -280,9 +280,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
         block_merge<float, long long, KS, MERGE_WAVES>(
             [&](long long c, float& key, long long& id) {
                 const long long l = c / k, j = c - l * k;
-                const long long o = (l * nq + q) * k + j;
-                id = Il[o];
-                const float v = Dl[o];
+                id = Il[l * stride_I + q * k + j];
+                const float v = Dl[l * stride_D + q * k + j];
                 key = ip ? v : -v;
                 return id >= 0;
             },
@@ -290,9 +289,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void ext_merge_kernel(
     } else {
         block_merge_lists<float, long long, KS, MERGE_WAVES>(
             [&](int l, int p, float& key, long long& id) {
-                const long long o = ((long long)l * nq + q) * k + p;
-                id = Il[o];
-                const float v = Dl[o];
+                id = Il[(long long)l * stride_I + q * k + p];
+                const float v = Dl[(long long)l * stride_D + q * k + p];
                 key = ip ? v : -v;
                 return id >= 0;
             },
@@ -1114,22 +1112,31 @@ int rag_flat_copy_to_host(rag_flat_t* h, int64_t first, int64_t n, float* out) {
     return RAG_OK;
 }
 
-int rag_topk_merge_dev(int metric, int nlists, int64_t nq, int k, const float* Dl, const int64_t* Il,
-                       float* D, int64_t* I, void* stream) {
+int rag_topk_merge_strided_dev(int metric, int nlists, int64_t nq, int k, const float* Dl, const int64_t* Il,
+                               int64_t stride_D, int64_t stride_I, float* D, int64_t* I, void* stream) {
     RAG_REQUIRE_INIT();
     if (nlists < 1 || nq < 0 || k < 1 || k > RAG_MAX_K || !Dl || !Il || !D || !I)
         return fail(RAG_ERR_INVALID_ARG, "bad argument to rag_topk_merge_dev");
+    if (stride_D < nq * k || stride_I < nq * k) return fail(RAG_ERR_INVALID_ARG, "list stride smaller than nq*k");
     if (metric != RAG_METRIC_IP && metric != RAG_METRIC_L2) return fail(RAG_ERR_INVALID_ARG, "bad metric");
     if (nq == 0) return RAG_OK;
     hipStream_t st = stream ? (hipStream_t)stream : lib_stream();
     const int KS = ks_for(k);
     const long long* Ill = reinterpret_cast<const long long*>(Il);
     long long* Io = reinterpret_cast<long long*>(I);
-    if (KS == 1) ext_merge_kernel<1><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io);
-    else if (KS == 2) ext_merge_kernel<2><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io);
-    else ext_merge_kernel<4><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io);
+    if (KS == 1)
+        ext_merge_kernel<1><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io, stride_D, stride_I);
+    else if (KS == 2)
+        ext_merge_kernel<2><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io, stride_D, stride_I);
+    else
+        ext_merge_kernel<4><<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, Dl, Ill, nlists, nq, k, D, Io, stride_D, stride_I);
     RAG_HIP(hipGetLastError());
     return RAG_OK;
+}
+
+int rag_topk_merge_dev(int metric, int nlists, int64_t nq, int k, const float* Dl, const int64_t* Il,
+                       float* D, int64_t* I, void* stream) {
+    return rag_topk_merge_strided_dev(metric, nlists, nq, k, Dl, Il, nq * (int64_t)k, nq * (int64_t)k, D, I, stream);
 }
 
 int rag_flat_profiling(rag_flat_t* h, int enable) {

@@ -122,6 +122,32 @@ class SearchEngine:
         results.sort(key=lambda x: x["score"], reverse=True)
         return results[:top_k]
 
+    def search_faiss_batch(self, queries, top_k=10, retrieval_mode="chunk") -> List[List[Dict[str, Any]]]:
+        """search_faiss for a list of queries with ONE index.search(nq x d) call -- the batched
+        front end the reference lacks (search_engine.py:141 is strictly one query).
+        Element i equals search_faiss(queries[i], top_k, retrieval_mode) up to near-ties between
+        the batch and single-query kernels (both within the 1e-5 dense tolerance)."""
+        queries = list(queries)
+        if "faiss" not in self.vector_storage.indices_present or not queries:
+            return [[] for _ in queries]
+        k = top_k * 3 if retrieval_mode == "document" else top_k
+        q_vecs = np.stack([np.asarray(self.embedding_manager.embed_query(q), dtype="float32").reshape(-1)
+                           for q in queries])
+        out = []
+        for query, hits in zip(queries, self.vector_storage.search_batch(q_vecs, top_k=k)):
+            for r in hits:
+                r["score"] = float(r["score"])
+            if retrieval_mode == "document":
+                groups = self._group_dense_by_doc(hits)
+                results = [{"doc_id": d, "score": g["score"], "text": " ".join(g["chunks"])} for d, g in groups.items()]
+            else:
+                results = hits
+            if self.cross_encoder:
+                results = self.rerank_with_cross_encoder(query, results, normalize_ce=True)
+            results.sort(key=lambda x: x["score"], reverse=True)
+            out.append(results[:top_k])
+        return out
+
     def search_bm25(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
         if "bm25" not in self.vector_storage.indices_present:
             return []

@@ -3,10 +3,10 @@
 SURVEY 8(e): rank r holds the contiguous row block [r*ceil(N/G), min(N, (r+1)*ceil(N/G)));
 global id = block base + local row.  A search broadcasts nothing (every rank is given the
 same query batch), runs the fused scan+top-k on its shard with id_base = block base, then the
-per-rank (nq x k) candidate lists are exchanged with ONE all-gather per array (RCCL over xGMI
-when the tensors are on the GPU: `backend="nccl"` is RCCL on ROCm) and merged on every rank
-(rag_topk_merge_dev: score best-first, lower global id first on ties).  This is the path's
-only exchange step; there is no all-reduce.
+per-rank (nq x k) candidate lists -- ids and scores packed in one buffer -- are exchanged with
+ONE all-gather (RCCL over xGMI when the tensors are on the GPU: `backend="nccl"` is RCCL on
+ROCm) and merged on every rank (rag_topk_merge_strided_dev: score best-first, lower global id
+first on ties).  This is the path's only exchange step; there is no all-reduce.
 
 The reference has no counterpart (single process, faiss-cpu); the merged result is by
 construction identical to searching one index that holds all rows (tests/test_flat_gpu.py
@@ -31,12 +31,16 @@ def shard_bounds(n_total, world):
 
 
 def _hip_merge(metric, D_all, I_all, D_out, I_out, stream):
-    """Device tensors [G, nq, k] -> [nq, k] through rag_topk_merge_dev."""
+    """Device tensors [G, nq, k] (views into the packed gather buffer: list stride != nq*k) ->
+    [nq, k] through rag_topk_merge_strided_dev."""
     lib = _lib.engine()
     G, nq, k = D_all.shape
-    _lib.check(lib.rag_topk_merge_dev(int(metric), int(G), int(nq), int(k), C.c_void_p(D_all.data_ptr()),
-                                      C.c_void_p(I_all.data_ptr()), C.c_void_p(D_out.data_ptr()),
-                                      C.c_void_p(I_out.data_ptr()), C.c_void_p(stream) if stream else None), lib)
+    assert D_all.stride(1) == k and D_all.stride(2) == 1 and I_all.stride(1) == k and I_all.stride(2) == 1
+    _lib.check(lib.rag_topk_merge_strided_dev(int(metric), int(G), int(nq), int(k), C.c_void_p(D_all.data_ptr()),
+                                              C.c_void_p(I_all.data_ptr()), int(D_all.stride(0)),
+                                              int(I_all.stride(0)), C.c_void_p(D_out.data_ptr()),
+                                              C.c_void_p(I_out.data_ptr()),
+                                              C.c_void_p(stream) if stream else None), lib)
 
 
 class ShardedFlatSearcher:
@@ -56,11 +60,16 @@ class ShardedFlatSearcher:
         self.metric, self.nq, self.k = int(metric), int(nq), int(k)
         self.local_search = local_search
         self.merge = merge or (lambda m, Da, Ia, Do, Io: _hip_merge(m, Da, Ia, Do, Io, stream))
-        self.D_loc = torch.empty((nq, k), dtype=torch.float32, device=device)
-        self.I_loc = torch.empty((nq, k), dtype=torch.int64, device=device)
+        # one packed buffer per rank: nq*k int64 ids, then nq*k float32 scores (padded to 8 bytes)
+        m = nq * k
+        words = m + (m + 1) // 2
+        self._pack = torch.zeros(words, dtype=torch.int64, device=device)
+        self.I_loc = self._pack[:m].view(nq, k)
+        self.D_loc = self._pack[m:].view(torch.float32)[:m].view(nq, k)
         if self.world > 1:
-            self.D_all = torch.empty((self.world, nq, k), dtype=torch.float32, device=device)
-            self.I_all = torch.empty((self.world, nq, k), dtype=torch.int64, device=device)
+            self._pack_all = torch.zeros((self.world, words), dtype=torch.int64, device=device)
+            self.I_all = self._pack_all[:, :m].view(self.world, nq, k)
+            self.D_all = self._pack_all[:, m:].view(torch.float32)[:, :m].view(self.world, nq, k)
             self.D_out = torch.empty((nq, k), dtype=torch.float32, device=device)
             self.I_out = torch.empty((nq, k), dtype=torch.int64, device=device)
         else:
@@ -71,7 +80,6 @@ class ShardedFlatSearcher:
         on the current stream for GPU tensors)."""
         self.local_search(q, self.k, self.D_loc, self.I_loc)
         if self.world > 1:
-            self._dist.all_gather_into_tensor(self.D_all.view(-1, self.k), self.D_loc, group=self.group)
-            self._dist.all_gather_into_tensor(self.I_all.view(-1, self.k), self.I_loc, group=self.group)
+            self._dist.all_gather_into_tensor(self._pack_all.view(-1), self._pack, group=self.group)
             self.merge(self.metric, self.D_all, self.I_all, self.D_out, self.I_out)
         return self.D_out, self.I_out

@@ -239,6 +239,28 @@ def test_sharded_search_and_device_merge(engine):
         # and the CPU restatement of the merge agrees bit for bit
         Dr, Ir = od.topk_merge(metric, Dl.cpu().numpy(), Il.cpu().numpy())
         assert np.array_equal(Ir, Iw) and np.array_equal(Dr, Dw)
+        # packed layout of the sharded searcher (ids then scores in one buffer per rank, one
+        # all-gather): the strided merge through the searcher's own views
+        from rag_system_amd.sharded import ShardedFlatSearcher, _hip_merge
+        m = nq * k
+        words = m + (m + 1) // 2
+        pack = torch.zeros((G, words), dtype=torch.int64, device=dev)
+        I_all = pack[:, :m].view(G, nq, k)
+        D_all = pack[:, m:].view(torch.float32)[:, :m].view(G, nq, k)
+        I_all.copy_(Il)
+        D_all.copy_(Dl)
+        Dm.zero_()
+        Im.zero_()
+        _hip_merge(metric, D_all, I_all, Dm, Im, st)
+        torch.cuda.synchronize()
+        assert np.array_equal(Im.cpu().numpy(), Iw) and np.array_equal(Dm.cpu().numpy(), Dw)
+        # single-rank searcher writes through the packed views too
+        s1 = ShardedFlatSearcher(lambda q, kk, Dloc, Iloc: whole._b.search_dev(nq, q.data_ptr(), kk, Dloc.data_ptr(),
+                                                                              Iloc.data_ptr(), 0, st),
+                                 metric, nq, k, dev, stream=st)
+        D1, I1 = s1.search(qd)
+        torch.cuda.synchronize()
+        assert np.array_equal(I1.cpu().numpy(), Iw) and np.array_equal(D1.cpu().numpy(), Dw)
 
 
 def test_full_size_10M_x_384_against_streaming_oracle(engine):
