@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <vector>
 
 namespace {
@@ -658,17 +659,22 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     const Options& opt = options();
     const int KS = ks_for(k > RAG_MAX_K ? RAG_MAX_K : k);
 
-    int rc = grow(h->ws_q, h->ws_q_cap, nq * ld);
-    if (rc) return rc;
-    if (bf) {
-        rc = grow(h->ws_qb, h->ws_qb_cap, nq * ld);
+    int rc = RAG_OK;
+    // fp32 rows whose length needs no padding: the kernels read the caller's queries directly
+    const bool q_direct = !bf && ld == h->d && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0;
+    const float* qf = q_dev;  // nq x ld fp32 queries as the kernels see them
+    if (!q_direct) {
+        rc = grow(h->ws_q, h->ws_q_cap, nq * ld);
         if (rc) return rc;
-    }
-    {
+        if (bf) {
+            rc = grow(h->ws_qb, h->ws_qb_cap, nq * ld);
+            if (rc) return rc;
+        }
         const long long total = nq * ld;
         pad_queries_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(q_dev, h->ws_q, bf ? h->ws_qb : nullptr, nq,
                                                                            h->d, ld);
         RAG_HIP(hipGetLastError());
+        qf = h->ws_q;
     }
 
     MfmaPlan plan;
@@ -715,7 +721,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             }
             rc = grow(h->ws_qn, h->ws_qn_cap, nq);
             if (rc) return rc;
-            rc = mfma_row_norms(h->ws_q, ld, false, 0, nq, h->ws_qn, st);
+            rc = mfma_row_norms(qf, ld, false, 0, nq, h->ws_qn, st);
             if (rc) return rc;
         }
         if (filter) {
@@ -748,7 +754,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         }
         // the kernel moves 16-byte chunks: both operands are addressed in 4-byte words
         const float* Xw = reinterpret_cast<const float*>(h->x);
-        const float* Qw = bf ? reinterpret_cast<const float*>(h->ws_qb) : h->ws_q;
+        const float* Qw = bf ? reinterpret_cast<const float*>(h->ws_qb) : qf;
         const int ldw = ld * h->esz / 4;
         merge_fn_t mf = pick_merge(KS, h->metric);
         if (!filter) {
@@ -866,7 +872,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                 RAG_HIP(hipEventRecord(e0, st));
             }
             fn<<<(unsigned)nb, SCAN_THREADS, smem, st>>>(reinterpret_cast<const f32x4*>(h->x), (long long)n, dch,
-                                                        reinterpret_cast<const f32x4*>(h->ws_q + q0 * ld), kp,
+                                                        reinterpret_cast<const f32x4*>(qf + q0 * ld), kp,
                                                         h->ws_key, h->ws_id, fl_k ? fl_k + q0 : nullptr,
                                                         fl_i ? fl_i + q0 : nullptr);
             RAG_HIP(hipGetLastError());

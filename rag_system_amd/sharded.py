@@ -70,10 +70,18 @@ class ShardedFlatSearcher:
             self._pack_all = torch.zeros((self.world, words), dtype=torch.int64, device=device)
             self.I_all = self._pack_all[:, :m].view(self.world, nq, k)
             self.D_all = self._pack_all[:, m:].view(torch.float32)[:, :m].view(self.world, nq, k)
-            self.D_out = torch.empty((nq, k), dtype=torch.float32, device=device)
-            self.I_out = torch.empty((nq, k), dtype=torch.int64, device=device)
+            self.out_packed = torch.zeros(words, dtype=torch.int64, device=device)
+            self.I_out = self.out_packed[:m].view(nq, k)
+            self.D_out = self.out_packed[m:].view(torch.float32)[:m].view(nq, k)
         else:
-            self.D_out, self.I_out = self.D_loc, self.I_loc
+            self.out_packed, self.D_out, self.I_out = self._pack, self.D_loc, self.I_loc
+
+    def unpack(self, packed):
+        """(D, I) views of a tensor with out_packed's layout (e.g. its pinned host copy: ONE copy
+        brings ids and scores back)."""
+        import torch
+        m = self.nq * self.k
+        return packed[m:].view(torch.float32)[:m].view(self.nq, self.k), packed[:m].view(self.nq, self.k)
 
     def search(self, q):
         """q: (nq, d) tensor on the searcher's device.  Returns (D_out, I_out) tensors (asynchronous
