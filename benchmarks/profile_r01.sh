@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/prof_r01; rm -rf $O; mkdir -p $O
 run() { name=$1; shift; timeout -s KILL 240 rocprofv3 "$@" > $O/$name.log 2>&1 || echo "$name failed"; }
-NQ1="bench.py --no-cpu-baseline --steps 50 --warmup 5"
+NQ1="bench.py --no-cpu-baseline --no-batch-leg --steps 50 --warmup 5"
 NQ1024="bench.py --no-cpu-baseline --nq 1024 --steps 3 --warmup 1"
 C3="bench.py --no-cpu-baseline --storage bf16 --dim 768 --k 100 --nq 1024 --steps 3 --warmup 1"
 run nq1_stats --kernel-trace --stats -d $O/nq1_stats --output-format csv -- python3 $NQ1

@@ -3,7 +3,7 @@ set -e
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/t_all.log 2>&1 || { tail -30 gpurun_out/t_all.log; exit 1; }
 tail -2 gpurun_out/t_all.log
 rm -f gpurun_out/c*.json gpurun_out/b_*.json
-B="timeout -k 10 150 python bench.py --no-cpu-baseline"
+B="timeout -k 10 150 python bench.py --no-cpu-baseline --no-batch-leg"
 $B > gpurun_out/b_nq1.json
 $B --k 100 > gpurun_out/b_nq1_k100.json
 $B --nq 4 > gpurun_out/b_nq4.json

@@ -1,5 +1,5 @@
 set -e
-B="timeout -k 10 150 python bench.py --no-cpu-baseline"
+B="timeout -k 10 150 python bench.py --no-cpu-baseline --no-batch-leg"
 $B --storage bf16 --dim 768 --k 100 --nq 1024 --steps 10 --warmup 2 > gpurun_out/c3_nq1024.json
 $B --storage bf16 --dim 768 --k 10 --nq 1024 --steps 10 --warmup 2 > gpurun_out/c3_nq1024_k10.json
 $B --storage bf16 --dim 768 --k 10 --nq 1024 --steps 10 --warmup 2 --opt mfma_shape=8 > gpurun_out/c3_nq1024_k10_s8.json

@@ -1,5 +1,5 @@
 set -e
-B="timeout -k 10 150 python bench.py --no-cpu-baseline"
+B="timeout -k 10 150 python bench.py --no-cpu-baseline --no-batch-leg"
 rm -f gpurun_out/m_*.json
 $B --storage bf16 --dim 768 --k 100 --nq 1024 --steps 10 --warmup 2 $EXTRA > gpurun_out/m_c3_k100.json
 $B --storage bf16 --dim 768 --k 10 --nq 1024 --steps 10 --warmup 2 $EXTRA > gpurun_out/m_c3_k10.json
