@@ -39,7 +39,7 @@ using mfma::Shape;
 bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     if (k > 128 || nq < 1 || n < 1) return false;
     const int KS = k > 64 ? 2 : 1;
-    int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 4));
+    int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));  // measured per batch size (benchmarks/run_nq64_sweep.sh)
     const long long force = options().mfma_shape;
     if (force >= 1 && force <= NSHAPES) shape = (int)force - 1;
     if (KS == 2 && SHAPES[shape].WM * SHAPES[shape].WN > 4) shape = SHAPES[shape].BK == 32 ? 6 : 2;
