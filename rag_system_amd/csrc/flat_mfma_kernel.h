@@ -1,13 +1,15 @@
-// flat_mfma_kernel.h -- query batches: exact-f32 MFMA GEMM tile fused with per-query top-k.
+// flat_mfma_kernel.h -- query batches: MFMA GEMM tile fused with per-query top-k.
 //
 // The one place the search path is a real dense contraction (BASELINE.json north_star):
-// S[row, q] = sum_k X[row, k] * Q[q, k] for nq >= 5 queries, followed by top-k over rows.
-// Uses v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit a k-ordered fmaf chain, no
-// TF32/xf32 on gfx950), peak 157 TFLOP/s = the bound for nq >~ 40 (ridge ~20 flop/B).
+// S[row, q] = sum_k X[row, k] * Q[q, k] for a batch of queries, followed by top-k over rows.
+// fp32 rows: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit a k-ordered fmaf chain,
+// no TF32/xf32 on gfx950), peak 157 TFLOP/s = the bound for nq >~ 40 (ridge ~20 flop/B).
+// bfloat16 rows: v_mfma_f32_32x32x16_bf16 (fp32 accumulate), peak ~2.5 PFLOP/s.
+// Two epilogues: list mode (described below) and filter mode (see the kernel's comment).
 //
 // Tiling (one workgroup = WM x WN waves, always 4 or 8 so every SIMD of the CU gets the same
 // number of waves):
-//   block tile   BM = 32*MT*WM rows  x  BN = 32*WN queries,  K step BK = 16 floats
+//   block tile   BM = 32*MT*WM rows  x  BN = 32*WN queries,  K step BK = 16 or 32 words
 //   wave (wm,wn) rows [32*MT*wm, +32*MT) x queries [32*wn, +32): MT accumulator tiles of 32x32.
 //                A wave owns its (row slice, query column) pairs outright: its top-k lists and
 //                thresholds are wave-private, no cross-wave synchronisation in the epilogue.

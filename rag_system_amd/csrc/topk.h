@@ -305,30 +305,6 @@ __device__ __forceinline__ float wave_multi_reduce(float (&v)[N], int lane) {
     return v[0];
 }
 
-// Largest k-th key over `nlists` sorted k-lists (kth_of_list(l) = key at position k-1 of list l,
-// Lowest if that position is a pad).  The list that holds it has k entries >= this value, so
-// no candidate below it can reach the merged top-k: merges drop those before any insertion.
-// red: LDS scratch of NWAVES keys.  Every thread of the block must call.
-template <typename KeyT, int NWAVES, class KthLoader>
-__device__ __forceinline__ KeyT block_max_kth(KthLoader kth_of_list, int nlists, KeyT* red) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    KeyT m = Lowest<KeyT>::v();
-    for (int l = tid; l < nlists; l += NWAVES * 64) {
-        const KeyT v = kth_of_list(l);
-        m = v > m ? v : m;
-    }
-    for (int dist = 32; dist >= 1; dist >>= 1) {
-        const KeyT o = __shfl_xor(m, dist);
-        m = o > m ? o : m;
-    }
-    if (lane == 0) red[wid] = m;
-    __syncthreads();
-    KeyT r = red[0];
-    for (int w = 1; w < NWAVES; ++w) r = red[w] > r ? red[w] : r;
-    __syncthreads();
-    return r;
-}
-
 // Block-wide merge of C candidate (key, id) pairs into one sorted k-list held by wave 0 of a
 // block of NWAVES waves.  `load(c, key, id)` returns the validity of candidate c in [0, C).
 // mk / mi: LDS scratch of (NWAVES-1)*KS*64 entries each.  Every thread of the block must call.
