@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
     const int shape = argc > 5 ? atoi(argv[5]) : 0;
     const int stages = argc > 6 ? atoi(argv[6]) : 0;
     const long long n = argc > 7 ? atoll(argv[7]) : 10000000LL;
+    const bool zeros = argc > 8 ? atoi(argv[8]) != 0 : false;  // all-zero operands: no data toggling (DVFS check)
     if (rag_init(0) != 0) { fprintf(stderr, "%s\n", rag_last_error()); return 1; }
     rag_set_option("mfma_shape", shape);
     rag_set_option("mfma_stages", stages);
@@ -44,8 +45,13 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&X, (size_t)n * ldw * 4));
     CK(hipMalloc(&Q, (size_t)(nq + 256) * ldw * 4));
     CK(hipMalloc(&zero, 64)); CK(hipMemset(zero, 0, 64));
-    fill_kernel<<<4096, 256>>>(X, (size_t)n * ldw, 1u, bf);
-    fill_kernel<<<256, 256>>>(Q, (size_t)(nq + 256) * ldw, 7u, bf);
+    if (zeros) {
+        CK(hipMemset(X, 0, (size_t)n * ldw * 4));
+        CK(hipMemset(Q, 0, (size_t)(nq + 256) * ldw * 4));
+    } else {
+        fill_kernel<<<4096, 256>>>(X, (size_t)n * ldw, 1u, bf);
+        fill_kernel<<<256, 256>>>(Q, (size_t)(nq + 256) * ldw, 7u, bf);
+    }
     rag::MfmaPlan p;
     if (!rag::mfma_plan(n, nq, k, bf, &p)) { fprintf(stderr, "no plan\n"); return 1; }
     CK(hipMalloc(&ck, (size_t)nq * p.nlists * k * 4)); CK(hipMalloc(&ci, (size_t)nq * p.nlists * k * 4));

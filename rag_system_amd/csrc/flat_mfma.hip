@@ -41,18 +41,19 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     const int KS = k > 64 ? 2 : 1;
     int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));  // measured per batch size (benchmarks/run_nq64_sweep.sh)
     const long long force = options().mfma_shape;
-    if (force >= 1 && force <= NSHAPES) shape = (int)force - 1;
+    if (force >= 1 && force <= NSHAPES) shape = (int)force - 1;  // 9, 10: 64-query wave tiles
     if (KS == 2 && SHAPES[shape].WM * SHAPES[shape].WN > 4) shape = SHAPES[shape].BK == 32 ? 6 : 2;
     int NS = 3;
     if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
+    const int NS0 = NS;
     int bpc = SHAPES[shape].bpc;
     if (options().mfma_bpc > 0) bpc = (int)options().mfma_bpc;
     // fit LDS: shrink the ring first, then fall back to a 4-wave shape (fewer per-wave lists)
     for (;;) {
         const Shape& sh = SHAPES[shape];
-        if (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.BK, NS, k) * bpc <= 160 * 1024) break;
+        if (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.NT, sh.BK, NS, k) * bpc <= 160 * 1024) break;
         if (NS > 2) { --NS; continue; }
-        if (bpc > 1) { --bpc; NS = 3; continue; }
+        if (bpc > 1) { --bpc; NS = NS0; continue; }
         if (shape != 2) { shape = 2; bpc = 1; NS = 3; continue; }
         return false;
     }
@@ -67,7 +68,7 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     p->filt = false;
     p->tile_step = 1;
     p->cap = 0;
-    const int BN = 32 * sh.WN, BM = 32 * sh.MT * sh.WM;
+    const int BN = 32 * sh.NT * sh.WN, BM = 32 * sh.MT * sh.WM;
     p->col_tiles = (int)((nq + BN - 1) / BN);
     const long long ntiles = (n + BM - 1) / BM;
     long long S = ((long long)num_cus() * bpc + p->col_tiles - 1) / p->col_tiles;
@@ -83,12 +84,12 @@ bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p
     if (nq < 1 || n < 1 || cap < 1) return false;
     int shape = nq > 128 ? 3 : 2;
     const long long force = options().mfma_shape;
-    if (force == 3 || force == 4 || force == 7 || force == 8) shape = (int)force - 1;
+    if (force == 3 || force == 4 || force == 7 || force == 8 || force == 9) shape = (int)force - 1;
     int NS = 3;
     if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
     const Shape& sh = SHAPES[shape];
     int bpc = sh.bpc;
-    while (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.BK, NS, 0) * bpc > 160 * 1024) {
+    while (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.NT, sh.BK, NS, 0) * bpc > 160 * 1024) {
         if (NS > 2) --NS;
         else if (bpc > 1) --bpc;
         else return false;
@@ -103,7 +104,7 @@ bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p
     p->filt = true;
     p->tile_step = 1;
     p->cap = cap;
-    const int BN = 32 * sh.WN, BM = 32 * sh.MT * sh.WM;
+    const int BN = 32 * sh.NT * sh.WN, BM = 32 * sh.MT * sh.WM;
     p->col_tiles = (int)((nq + BN - 1) / BN);
     const long long ntiles = (n + BM - 1) / BM;
     long long S = ((long long)num_cus() * bpc + p->col_tiles - 1) / p->col_tiles;

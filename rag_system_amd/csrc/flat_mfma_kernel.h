@@ -97,7 +97,7 @@ __device__ unsigned long long g_mfma_timing[8];
 // tile_step: only row tiles t*tile_step are visited (1 = all; the sample pass uses > 1).
 // run_flag: if non-null and *run_flag == 0 the kernel returns at once (the list-mode redo is
 //   enqueued unconditionally and costs a launch when nothing failed).
-template <int WM, int WN, int MT, int BK, int NS, int KS, int METRIC, bool BF, bool FILT>
+template <int WM, int WN, int MT, int NT, int BK, int NS, int KS, int METRIC, bool BF, bool FILT>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma_kernel(
     const float* __restrict__ X, long long n, int ld, const float* __restrict__ Qp, int nq, int k, int S,
     int col_tiles, float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
     constexpr int T = 64 * NWV;
     constexpr int BMW = 32 * MT;          // rows per wave
     constexpr int BM = BMW * WM;
-    constexpr int BN = 32 * WN;
+    constexpr int BNW = 32 * NT;          // queries per wave
+    constexpr int BN = BNW * WN;
     constexpr int CH = BK / 4;            // 16-byte chunks per tile row
     constexpr int LDS_LD = BK;            // tile row stride in floats
     constexpr int XI = BM * CH / 64;      // wave-instructions (1 KiB each) per X tile
@@ -124,9 +125,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
     float* Qs = Xs + NS * BM * LDS_LD;                              // [NS][BN][LDS_LD]
     float* dummy = Qs + NS * BN * LDS_LD;                           // [256] sink of filler loads
     const int kl = FILT ? 0 : k;                                    // list entries held in LDS
-    float* lkey = dummy + 256;                                      // [NWV][32][kl]
-    int* lid = reinterpret_cast<int*>(lkey + NWV * 32 * kl);        // [NWV][32][kl]
-    float* scratch = reinterpret_cast<float*>(lid + NWV * 32 * kl); // [NWV][32]
+    float* lkey = dummy + 256;                                      // [NWV][BNW][kl]
+    int* lid = reinterpret_cast<int*>(lkey + NWV * BNW * kl);       // [NWV][BNW][kl]
+    float* scratch = reinterpret_cast<float*>(lid + NWV * BNW * kl);// [NWV][32]
     float* xn_s = scratch + NWV * 32;                               // [BM] row norms (L2 only)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -153,17 +154,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
     const long long total = my_tiles * nk;
 
     // lists start as pads
-    for (int i = tid; i < NWV * 32 * kl; i += T) {
+    for (int i = tid; i < NWV * BNW * kl; i += T) {
         lkey[i] = Lowest<float>::v();
         lid[i] = IdPad<int>::v();
     }
-    const int my_q = q0 + 32 * wn + li;  // this lane's query
-    // list mode: current k-th key of this lane's query (within this wave's rows);
-    // filter mode: the query's fixed threshold (padding queries never pass)
-    float thr = Lowest<float>::v();
-    if (FILT) thr = my_q < nq ? thr_q[my_q] : FLT_MAX;
-    float qn = 0.f;
-    if (METRIC == RAG_METRIC_L2) qn = my_q < nq ? qnorm[my_q] : 0.f;
+    // this lane's NT queries.  thr: list mode: current k-th key of the query (within this wave's
+    // rows); filter mode: the query's fixed threshold (padding queries never pass)
+    int my_q[NT];
+    float thr[NT], qn[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        my_q[u] = q0 + BNW * wn + 32 * u + li;
+        thr[u] = Lowest<float>::v();
+        if (FILT) thr[u] = my_q[u] < nq ? thr_q[my_q[u]] : FLT_MAX;
+        qn[u] = 0.f;
+        if (METRIC == RAG_METRIC_L2) qn[u] = my_q[u] < nq ? qnorm[my_q[u]] : 0.f;
+    }
 
     // Direct-to-LDS tile loads.  LDS slot s (16 B) of a tile holds row s/CH, physical chunk s%CH =
     // logical chunk (s%CH) ^ swz(row).  A wave instruction fills 64 consecutive slots;
@@ -242,11 +248,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
 
     // accumulators are cleared after each row tile's epilogue (inside its uniform branch), not
     // by a per-K-step select
-    f32x16 acc[MT];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
     using TK = WaveTopK<float, int, KS>;
 
     // NS-stage ring: stages e .. e+NS-2 are in flight at the top of iteration e.
@@ -285,28 +293,55 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                     RAG_TMARK(2)
                     int nxt = cur + NS - 1;
                     nxt = nxt >= NS ? nxt - NS : nxt;
+#if defined(RAG_MFMA_TIMING) && defined(RAG_EXP_NO_GLDS)
+                    if (e < 4) issue_loads(nxt);
+                    else {
+#pragma unroll
+                        for (int part = 0; part < LPS; ++part) glds16(zero16, dummy);
+                    }
+#else
                     issue_loads(nxt);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int pc = ((kk * 2 + lh) ^ sw) * 4;
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(qs + (32 * wn + li) * LDS_LD + pc);
-                f32x4 a[MT];
+                f32x4 bq[NT], a[MT];
+#if defined(RAG_MFMA_TIMING) && defined(RAG_EXP_NO_LDSREAD)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) bq[u] = f32x4{1.f * pc, 2.f, 3.f, 4.f};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[t] = f32x4{1.f * t, 2.f * pc, 3.f, 4.f};
+#else
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    bq[u] = *reinterpret_cast<const f32x4*>(qs + (BNW * wn + 32 * u + li) * LDS_LD + pc);
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
                     a[t] = *reinterpret_cast<const f32x4*>(xs + (32 * t + li) * LDS_LD + pc);
-                if (BF) {
-                    const bf16x8 bqh = __builtin_bit_cast(bf16x8, bq);
+#endif
+#if defined(RAG_MFMA_TIMING) && defined(RAG_EXP_NO_MFMA)
 #pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t]), bqh, acc[t],
-                                                                         0, 0, 0);
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t][u][0] += a[t][0] * bq[u][1];
+#else
+                if (BF) {
+#pragma unroll
+                    for (int u = 0; u < NT; ++u)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, a[t]), __builtin_bit_cast(bf16x8, bq[u]), acc[t][u], 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-                        for (int t = 0; t < MT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][cc], bq[cc], acc[t], 0, 0, 0);
+                        for (int u = 0; u < NT; ++u)
+#pragma unroll
+                            for (int t = 0; t < MT; ++t)
+                                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][cc], bq[u][cc], acc[t][u], 0, 0, 0);
                 }
+#endif
             }
         }
         RAG_TMARK(3)
@@ -322,7 +357,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                 __syncthreads();
             }
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
                 const int tile_off = wm * BMW + 32 * t;
                 const long long rowbase = row0 + tile_off;
                 float key[16];
@@ -330,24 +367,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = acc[t][r];
-                    if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn_s[tile_off + ro]) - qn;
+                    float v = acc[t][u][r];
+                    if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn_s[tile_off + ro]) - qn[u];
                     key[r] = v;
-                    bool ok = FILT ? v >= thr : v > thr;
+                    bool ok = FILT ? v >= thr[u] : v > thr[u];
                     if (partial) ok = ok && (rowbase + ro < n);
                     any = any || ok;
                 }
                 const unsigned long long m = __ballot(any);
                 if (FILT) {
-                    if (m != 0ULL && my_q < nq) {
+                    if (m != 0ULL && my_q[u] < nq) {
                         // rare: append every passing row of this lane's query to its buffer
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            if (key[r] >= thr && rowbase + ro < n) {
-                                const unsigned int slot = atomicAdd(&counts[my_q], 1u);
+                            if (key[r] >= thr[u] && rowbase + ro < n) {
+                                const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
                                 if (slot < (unsigned int)cap) {
-                                    const long long o = (long long)my_q * cap + slot;
+                                    const long long o = (long long)my_q[u] * cap + slot;
                                     cand_key[o] = key[r];
                                     cand_id[o] = (int)(rowbase + ro);
                                 }
@@ -368,7 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                         const float cs = sc[li];
                         const long long crow = rowbase + li;
                         TK tk;
-                        const int lo = (32 * wid + j) * k;
+                        const int lo = ((wid * NT + u) * 32 + j) * k;
 #pragma unroll
                         for (int sl = 0; sl < KS; ++sl) {
                             const int p = sl * 64 + lane;
@@ -387,12 +424,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
                                 lid[lo + p] = tk.id[sl];
                             }
                         }
-                        if (li == j) thr = thr_k;
+                        if (li == j) thr[u] = thr_k;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
             }
         }
         RAG_TMARK(4)
@@ -414,10 +451,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
 
     // ---- list mode: write the lists of every real query: cand[q][s*WM + wm][k]
     __syncthreads();
-    for (int i = tid; i < NWV * 32 * kl; i += T) {
-        const int w = i / (32 * k), rem = i - w * 32 * k;
-        const int j = rem / k, p = rem - j * k;
-        const int qi = q0 + 32 * (w % WN) + j;
+    for (int i = tid; i < NWV * BNW * kl; i += T) {
+        const int w = i / (BNW * k), rem = i - w * BNW * k;
+        const int j = rem / k, p = rem - j * k;   // j = 32*u + lane-in-tile
+        const int qi = q0 + BNW * (w % WN) + j;
         if (qi < nq) {
             const long long o = ((long long)qi * (S * WM) + (long long)s * WM + (w / WN)) * k + p;
             cand_key[o] = lkey[i];
@@ -426,9 +463,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 8 ? 4 : 2)) void flat_mfma
     }
 }
 
-inline size_t smem_need(int WM, int WN, int MT, int BK, int NS, int k) {
-    const size_t BM = 32 * (size_t)MT * WM, BN = 32 * (size_t)WN, NWV = (size_t)WM * WN;
-    return NS * (BM + BN) * BK * 4 + 1024 + NWV * 32 * (size_t)k * 8 + NWV * 128 + BM * 4;
+inline size_t smem_need(int WM, int WN, int MT, int NT, int BK, int NS, int k) {
+    const size_t BM = 32 * (size_t)MT * WM, BN = 32 * (size_t)NT * WN, NWV = (size_t)WM * WN;
+    return NS * (BM + BN) * BK * 4 + 1024 + NWV * 32 * NT * (size_t)k * 8 + NWV * 128 + BM * 4;
 }
 
 struct Args {
@@ -446,11 +483,11 @@ struct Args {
     unsigned int* counts;    // filter mode: per-query append counters (zeroed by the caller)
 };
 
-template <int WM, int WN, int MT, int BK, int NS, int KS, bool BF, bool FILT>
+template <int WM, int WN, int MT, int NT, int BK, int NS, int KS, bool BF, bool FILT>
 int launch(const MfmaPlan& p, const Args& a) {
-    const size_t smem = smem_need(WM, WN, MT, BK, NS, FILT ? 0 : a.k);
-    auto fn = a.metric == RAG_METRIC_IP ? flat_mfma_kernel<WM, WN, MT, BK, NS, KS, RAG_METRIC_IP, BF, FILT>
-                                        : flat_mfma_kernel<WM, WN, MT, BK, NS, KS, RAG_METRIC_L2, BF, FILT>;
+    const size_t smem = smem_need(WM, WN, MT, NT, BK, NS, FILT ? 0 : a.k);
+    auto fn = a.metric == RAG_METRIC_IP ? flat_mfma_kernel<WM, WN, MT, NT, BK, NS, KS, RAG_METRIC_IP, BF, FILT>
+                                        : flat_mfma_kernel<WM, WN, MT, NT, BK, NS, KS, RAG_METRIC_L2, BF, FILT>;
     if (smem > 48 * 1024)
         RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem));
@@ -463,17 +500,19 @@ int launch(const MfmaPlan& p, const Args& a) {
 
 // The block shapes that are built.  bpc = blocks per CU the grid is sized for.
 struct Shape {
-    int WM, WN, MT, BK, bpc;
+    int WM, WN, MT, NT, BK, bpc;
 };
 constexpr Shape SHAPES[] = {
-    {4, 1, 2, 16, 2},  // 1: <= 32 queries, 256 rows
-    {2, 2, 4, 16, 2},  // 2: <= 64 queries, 256 rows
-    {1, 4, 8, 16, 2},  // 3: <= 128 queries, 256 rows, two decoupled 4-wave blocks per CU
-    {1, 8, 8, 16, 1},  // 4: 256 queries, 256 rows, one 8-wave block per CU
-    {4, 1, 2, 32, 1},  // 5: <= 32 queries, whole 128-byte lines
-    {2, 2, 4, 32, 1},  // 6: <= 64 queries
-    {1, 4, 8, 32, 1},  // 7: <= 128 queries
-    {1, 8, 8, 32, 1},  // 8: 256 queries
+    {4, 1, 2, 1, 16, 2},  // 1: <= 32 queries, 256 rows
+    {2, 2, 4, 1, 16, 2},  // 2: <= 64 queries, 256 rows
+    {1, 4, 8, 1, 16, 2},  // 3: <= 128 queries, 256 rows, two decoupled 4-wave blocks per CU
+    {1, 8, 8, 1, 16, 1},  // 4: 256 queries, 256 rows, one 8-wave block per CU
+    {4, 1, 2, 1, 32, 1},  // 5: <= 32 queries, whole 128-byte lines
+    {2, 2, 4, 1, 32, 1},  // 6: <= 64 queries
+    {1, 4, 8, 1, 32, 1},  // 7: <= 128 queries
+    {1, 8, 8, 1, 32, 1},  // 8: 256 queries
+    {2, 4, 4, 2, 16, 1},  // 9: 256 queries x 256 rows, wave tile 128 rows x 64 queries (6 fragment reads per
+                          //    8 MFMAs instead of 9); measured equal to shape 4, kept as an option
 };
 constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
@@ -483,16 +522,17 @@ constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 // no lists and is built for the (1,4,8) and (1,8,8) shapes.
 template <bool BF>
 int dispatch(const MfmaPlan& p, const Args& a) {
-#define RAG_MFMA_NS(WM, WN, MT, BK, KS, FILT) \
-    (p.NS >= 3 ? launch<WM, WN, MT, BK, 3, KS, BF, FILT>(p, a) : launch<WM, WN, MT, BK, 2, KS, BF, FILT>(p, a))
+#define RAG_MFMA_NS(WM, WN, MT, NT, BK, KS, FILT)                               \
+    (p.NS >= 3 ? launch<WM, WN, MT, NT, BK, 3, KS, BF, FILT>(p, a) : launch<WM, WN, MT, NT, BK, 2, KS, BF, FILT>(p, a))
 #define RAG_MFMA_4W(WM, WN, MT, BK) \
-    (p.KS == 2 ? RAG_MFMA_NS(WM, WN, MT, BK, 2, false) : RAG_MFMA_NS(WM, WN, MT, BK, 1, false))
+    (p.KS == 2 ? RAG_MFMA_NS(WM, WN, MT, 1, BK, 2, false) : RAG_MFMA_NS(WM, WN, MT, 1, BK, 1, false))
     if (p.filt) {
         switch (p.shape) {
-            case 2: return RAG_MFMA_NS(1, 4, 8, 16, 1, true);
-            case 3: return RAG_MFMA_NS(1, 8, 8, 16, 1, true);
-            case 6: return RAG_MFMA_NS(1, 4, 8, 32, 1, true);
-            case 7: return RAG_MFMA_NS(1, 8, 8, 32, 1, true);
+            case 2: return RAG_MFMA_NS(1, 4, 8, 1, 16, 1, true);
+            case 3: return RAG_MFMA_NS(1, 8, 8, 1, 16, 1, true);
+            case 6: return RAG_MFMA_NS(1, 4, 8, 1, 32, 1, true);
+            case 7: return RAG_MFMA_NS(1, 8, 8, 1, 32, 1, true);
+            case 8: return RAG_MFMA_NS(2, 4, 4, 2, 16, 1, true);
             default: return fail(RAG_ERR_INVALID_ARG, "no filter-mode kernel for block shape %d", p.shape + 1);
         }
     }
@@ -500,11 +540,12 @@ int dispatch(const MfmaPlan& p, const Args& a) {
         case 0: return RAG_MFMA_4W(4, 1, 2, 16);
         case 1: return RAG_MFMA_4W(2, 2, 4, 16);
         case 2: return RAG_MFMA_4W(1, 4, 8, 16);
-        case 3: return RAG_MFMA_NS(1, 8, 8, 16, 1, false);
+        case 3: return RAG_MFMA_NS(1, 8, 8, 1, 16, 1, false);
         case 4: return RAG_MFMA_4W(4, 1, 2, 32);
         case 5: return RAG_MFMA_4W(2, 2, 4, 32);
         case 6: return RAG_MFMA_4W(1, 4, 8, 32);
-        default: return RAG_MFMA_NS(1, 8, 8, 32, 1, false);
+        case 7: return RAG_MFMA_NS(1, 8, 8, 1, 32, 1, false);
+        default: return RAG_MFMA_NS(2, 4, 4, 2, 16, 1, false);
     }
 #undef RAG_MFMA_4W
 #undef RAG_MFMA_NS

@@ -116,7 +116,7 @@ def test_every_block_shape_gives_the_same_result(engine):
     try:
         for k in (16, 100):
             base = None
-            for shape in range(1, 9):
+            for shape in range(1, 10):
                 for stages in (2, 3):
                     _lib.check(lib.rag_set_option(b"mfma_shape", shape))
                     _lib.check(lib.rag_set_option(b"mfma_stages", stages))

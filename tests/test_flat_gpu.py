@@ -358,7 +358,7 @@ def test_every_mfma_block_shape_and_ring_depth(engine):
     _, Ir, D64 = od.flat_search(X, Q, 16, 0)
     base = None
     try:
-        for shape in range(1, 9):
+        for shape in range(1, 10):
             for stages in (2, 3):
                 _lib.check(lib.rag_set_option(b"mfma_shape", shape))
                 _lib.check(lib.rag_set_option(b"mfma_stages", stages))
