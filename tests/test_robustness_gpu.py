@@ -1,0 +1,135 @@
+"""GPU robustness tests of the dense index through the C ABI: concurrent callers on one handle
+(the reference UI starts a thread per query / ingest with no lock, UI_manager.py:753,883),
+argument validation, non-finite inputs, extreme shapes."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import dense as od
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+    return x
+
+
+def test_concurrent_add_and_search_on_one_handle(engine):
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(17)
+    d = 96
+    base = _rand_unit(rng, 5000, d)
+    extra = _rand_unit(rng, 4000, d)
+    Q = _rand_unit(rng, 6, d)
+    idx = faiss.IndexFlatIP(d)
+    idx.add(base)
+    errors = []
+
+    def adder(lo, hi):
+        try:
+            for i in range(lo, hi):
+                idx.add(extra[i:i + 1])                  # the reference's one-row add_vector pattern
+        except Exception as e:                           # pragma: no cover
+            errors.append(e)
+
+    def searcher():
+        try:
+            for _ in range(60):
+                D, I = idx.search(Q, 10)
+                n_now = idx.ntotal
+                assert ((I >= 0) & (I < n_now + 4000)).all()
+                assert (D[:, :-1] >= D[:, 1:]).all()
+        except Exception as e:                           # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=adder, args=(0, 2000)), threading.Thread(target=adder, args=(2000, 4000)),
+               threading.Thread(target=searcher), threading.Thread(target=searcher)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert idx.ntotal == 9000
+    # the two adders interleaved: the index holds the same multiset of rows; results match the
+    # oracle evaluated on the index's own row order
+    X = idx.reconstruct_n(0, 9000)
+    assert sorted(map(bytes, X[5000:])) == sorted(map(bytes, extra))
+    D, I = idx.search(Q, 10)
+    _, Ir, D64 = od.flat_search(X, Q, 10, 0)
+    od.check_topk(D, I, D64, Ir, 1e-5, 2e-6, lambda qi, ids: X[ids].astype(np.float64) @ Q[qi].astype(np.float64))
+
+
+def test_argument_validation_through_the_c_abi(engine):
+    from rag_system_amd import _lib
+    lib = _lib.engine()
+    h = C.c_void_p()
+    assert lib.rag_flat_create(0, 0, 0, C.byref(h)) == -1 and b"d=0" in lib.rag_last_error()
+    assert lib.rag_flat_create(16, 7, 0, C.byref(h)) == -1
+    assert lib.rag_flat_create(16, 0, 9, C.byref(h)) == -1
+    _lib.check(lib.rag_flat_create(16, 0, 0, C.byref(h)), lib)
+    x = np.zeros((4, 16), np.float32)
+    q = np.zeros((1, 16), np.float32)
+    D = np.zeros((1, 4), np.float32)
+    I = np.zeros((1, 4), np.int64)
+    assert lib.rag_flat_add(h, -1, _lib.ptr(x)) == -1
+    assert lib.rag_flat_add(h, 4, None) == -1
+    _lib.check(lib.rag_flat_add(h, 4, _lib.ptr(x)), lib)
+    assert lib.rag_flat_search(h, 1, _lib.ptr(q), 0, _lib.ptr(D), _lib.ptr(I)) == -1
+    assert lib.rag_flat_search(h, 1, _lib.ptr(q), 16385, _lib.ptr(D), _lib.ptr(I)) == -1
+    assert lib.rag_flat_search(h, 1, None, 4, _lib.ptr(D), _lib.ptr(I)) == -1
+    assert lib.rag_flat_search(None, 1, _lib.ptr(q), 4, _lib.ptr(D), _lib.ptr(I)) == -1
+    assert lib.rag_flat_copy_to_host(h, 2, 3, _lib.ptr(x)) == -1           # beyond ntotal
+    assert lib.rag_set_option(b"no_such_option", 1) == -1
+    assert lib.rag_topk_merge_dev(0, 0, 1, 4, _lib.ptr(D), _lib.ptr(I), _lib.ptr(D), _lib.ptr(I), None) == -1
+    _lib.check(lib.rag_flat_search(h, 0, None, 4, None, None), lib)        # nq = 0 is a no-op
+    _lib.check(lib.rag_flat_search(h, 1, _lib.ptr(q), 4, _lib.ptr(D), _lib.ptr(I)), lib)
+    assert I.tolist() == [[0, 1, 2, 3]]                                    # all-equal scores: id order
+    lib.rag_flat_free(h)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_non_finite_rows_never_displace_finite_ones(engine, storage):
+    """A NaN score compares false against everything, so such rows are never selected (faiss
+    leaves this unspecified); +-inf scores order like any other value."""
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(23)
+    n, d = 3000, 64
+    X = _rand_unit(rng, n, d)
+    X[10, 3] = np.nan
+    X[11] = np.inf
+    X[2000, 0] = -np.inf
+    Q = np.abs(_rand_unit(rng, 12, d)) + 0.01          # positive queries: row 11 scores +inf, row 2000 -inf
+    idx = faiss.IndexFlat(d, 0, storage=storage)
+    idx.add(X)
+    for nq in (1, 12):
+        D, I = idx.search(Q[:nq], 10)
+        assert not np.isnan(D).any()
+        assert (I[:, 0] == 11).all() and np.isposinf(D[:, 0]).all()
+        assert not (I == 10).any() and not (I == 2000).any()
+        finite = np.ones(n, bool)
+        finite[[10, 11, 2000]] = False
+        rnd = od.bf16_round if storage == "bf16" else (lambda a: a)
+        Xf, Qr = rnd(X[finite]), rnd(Q[:nq])
+        ids = np.flatnonzero(finite)
+        _, Ir, D64 = od.flat_search(Xf, Qr, 9, 0)
+        od.check_topk(D[:, 1:], I[:, 1:], D64, ids[Ir], 1e-5, 2e-6,
+                      lambda qi, rows: rnd(X[rows]).astype(np.float64) @ Qr[qi].astype(np.float64))
+
+
+def test_extreme_shapes(engine):
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(31)
+    for d, n, nq, k in [(1, 500, 3, 7), (2, 64, 70, 64), (8192, 40, 2, 5), (3, 1, 9, 3), (4097, 33, 5, 33)]:
+        X, Q = _rand_unit(rng, n, d), _rand_unit(rng, nq, d)   # the tolerance is stated for normalised rows
+        for metric in (0, 1):
+            idx = faiss.IndexFlat(d, metric)
+            idx.add(X)
+            D, I = idx.search(Q, k)
+            _, Ir, D64 = od.flat_search(X, Q, k, metric)
+            X64, Q64 = X.astype(np.float64), Q.astype(np.float64)
+            od.check_topk(D, I, D64, Ir, 1e-5, 2e-6,
+                          lambda qi, ids: (X64[ids] @ Q64[qi]) if metric == 0 else ((X64[ids] - Q64[qi]) ** 2).sum(1))
