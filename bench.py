@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (A/B runs)")
+    ap.add_argument("--dump-result", default=None, help="write the last step's (D, I) to this .npz (rank 0)")
     ap.add_argument("--no-batch-leg", action="store_true",
                     help="skip the extra batch-1024 measurement reported beside the batch-1 headline")
     return ap.parse_args()
@@ -104,12 +105,22 @@ def main():
     from rag_system_amd import _lib, faiss_compat as faiss
     from rag_system_amd.sharded import ShardedFlatSearcher
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RAG_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo as the transport -- a functional
+    # rehearsal of the N > 1 path on a one-GPU box (never a performance number)
+    rehearsal = os.environ.get("RAG_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        import faulthandler
+        faulthandler.dump_traceback_later(60, exit=True)   # a stuck rehearsal names its line
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    lib = _lib.engine(local_rank)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.engine(dev_index)
     for o in args.opt:
         name, val = o.split("=")
         _lib.check(lib.rag_set_option(name.encode(), int(val)))
@@ -215,6 +226,8 @@ def main():
         Dn, In = D_host.numpy(), I_host.numpy()
         assert ((In >= 0) & (In < n)).all(), "ids out of range"
         assert (Dn[:, :-1] >= Dn[:, 1:]).all(), "scores not sorted best-first"
+        if args.dump_result:
+            np.savez(args.dump_result, D=Dn, I=In)
         ms_per_step = elapsed / args.steps * 1e3
         qps = nq * args.steps / elapsed
         avg_scan_ms = scan_ms / max(n_launch, 1)
@@ -250,7 +263,8 @@ def main():
                       % (k, n // 1_000_000, d, "bf16" if bf else "fp32", nq),
             "value": qps, "unit": "QPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16" if bf else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if bf else "f32",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else ""),
             "config": {"workload": "%d x %d %s L2-normalised synthetic rows (seed %d), IndexFlatIP top-%d, nq=%d"
                                    % (n, d, "bf16" if bf else "fp32", args.seed, k, nq),
                        "rows": n, "dim": d, "k": k, "nq": nq, "storage": args.storage,

@@ -160,6 +160,8 @@ def engine(device=None):
     global _inited_device
     lib = load_library()
     if device is None:
+        if _inited_device is not None:      # whoever initialised the process chose the device
+            return lib
         device = int(os.environ.get("RAG_MI355X_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     with _lock:
         if _inited_device is None:
