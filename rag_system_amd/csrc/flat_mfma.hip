@@ -82,9 +82,9 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
 
 bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p) {
     if (nq < 1 || n < 1 || cap < 1) return false;
-    int shape = nq > 128 ? 3 : 2;
+    int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));
     const long long force = options().mfma_shape;
-    if (force == 3 || force == 4 || force == 7 || force == 8 || force == 9) shape = (int)force - 1;
+    if ((force >= 1 && force <= 4) || force == 7 || force == 8 || force == 9) shape = (int)force - 1;
     int NS = 3;
     if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
     const Shape& sh = SHAPES[shape];

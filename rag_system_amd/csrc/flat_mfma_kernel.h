@@ -519,7 +519,7 @@ constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 // One translation unit per element type instantiates its kernels behind this dispatcher
 // (flat_mfma_f32.hip / flat_mfma_bf16.hip).  List mode: KS = 2 (64 < k <= 128) exists for the
 // 4-wave shapes only (eight waves' lists of that length do not fit the LDS).  Filter mode holds
-// no lists and is built for the (1,4,8) and (1,8,8) shapes.
+// no lists and is built for the 64-byte-row shapes (1-4, 9) and the 128-byte-row shapes 7, 8.
 template <bool BF>
 int dispatch(const MfmaPlan& p, const Args& a) {
 #define RAG_MFMA_NS(WM, WN, MT, NT, BK, KS, FILT)                               \
@@ -528,6 +528,8 @@ int dispatch(const MfmaPlan& p, const Args& a) {
     (p.KS == 2 ? RAG_MFMA_NS(WM, WN, MT, 1, BK, 2, false) : RAG_MFMA_NS(WM, WN, MT, 1, BK, 1, false))
     if (p.filt) {
         switch (p.shape) {
+            case 0: return RAG_MFMA_NS(4, 1, 2, 1, 16, 1, true);
+            case 1: return RAG_MFMA_NS(2, 2, 4, 1, 16, 1, true);
             case 2: return RAG_MFMA_NS(1, 4, 8, 1, 16, 1, true);
             case 3: return RAG_MFMA_NS(1, 8, 8, 1, 16, 1, true);
             case 6: return RAG_MFMA_NS(1, 4, 8, 1, 32, 1, true);
