@@ -27,7 +27,7 @@ struct Options {
     int64_t mfma_shape = 0;    // force MFMA block shape 1..8 (0 = by batch size)
     int64_t mfma_stages = 0;   // force LDS ring depth 2..3 (0 = auto)
     int64_t mfma_bpc = 0;      // force MFMA blocks per CU used to size the row split (0 = auto)
-    int64_t mfma_filter_k = 33;            // k >= this -> MFMA filter mode (threshold + append)
+    int64_t mfma_filter_k = 0;             // k >= this -> MFMA filter mode (0 = auto: 16 up to 128 queries, else 33)
     int64_t mfma_filter_min_rows = 1 << 19;  // ... on shards of at least this many rows
 };
 Options& options();

@@ -694,7 +694,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         int cap = 1024;
         while (cap < j * FILTER_STEP + 8 * FILTER_STEP * (int)std::ceil(std::sqrt((double)j))) cap *= 2;
         MfmaPlan ps, pf;
-        const bool filter = k >= opt.mfma_filter_k && n >= opt.mfma_filter_min_rows &&
+        // measured crossover (benchmarks/run_filter_k.sh): nq = 64: filter mode wins from k = 16;
+        // nq = 1024 (one list per query and block): from k = 32
+        const int64_t filter_k = opt.mfma_filter_k > 0 ? opt.mfma_filter_k : (nq <= 128 ? 16 : 33);
+        const bool filter = k >= filter_k && n >= opt.mfma_filter_min_rows &&
                             mfma_plan(std::max<long long>(1, n / FILTER_STEP), nq, j, bf, &ps) &&
                             mfma_plan_filter(n, nq, bf, cap, &pf);
         int64_t need = nq * plan.nlists * k;

@@ -428,7 +428,7 @@ def test_mfma_filter_mode_matches_oracle(engine, storage):
             if name in ("all_equal", "ties_at_top"):
                 assert np.array_equal(I[0], Ir[0]), name          # exact ties: lower id first
     finally:
-        _with_options(lib, {"mfma_filter_k": 33, "mfma_filter_min_rows": 1 << 19})
+        _with_options(lib, {"mfma_filter_k": 0, "mfma_filter_min_rows": 1 << 19})
 
 
 def test_mfma_filter_mode_default_thresholds(engine):
@@ -447,5 +447,5 @@ def test_mfma_filter_mode_default_thresholds(engine):
         _with_options(lib, {"mfma_filter_k": 1000})
         D2, I2 = idx.search(Q, 50)
     finally:
-        _with_options(lib, {"mfma_filter_k": 33})
+        _with_options(lib, {"mfma_filter_k": 0})
     assert np.array_equal(I, I2) and np.array_equal(D, D2)
