@@ -820,7 +820,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         return RAG_OK;
     }
 
-    int64_t blocks = opt.scan_blocks > 0 ? opt.scan_blocks : (int64_t)num_cus() * 4;
+    // waves per CU (benchmarks/run_scan_threads_ab.sh): fp32 rows stream fastest with 12 (10M x 384:
+    // 2.19 ms against 2.215 ms with 16; 14 and 10 are slower), bfloat16 rows need 16 to cover the
+    // unpacking (2.28 ms against 2.63 ms with 12)
+    int64_t blocks = opt.scan_blocks > 0 ? opt.scan_blocks : (int64_t)num_cus() * (bf ? 4 : 3);
     int Rsel = (opt.scan_rows == 2 || opt.scan_rows == 8) ? (int)opt.scan_rows : 4;
 
     // k <= 256: one pass.  Larger k: passes of <= 256, each bounded by the previous pass' last entry.
