@@ -20,6 +20,7 @@
 //   * flat_merge_kernel (one block per query) merges the per-block lists.
 #include "common.h"
 #include "flat_mfma.h"
+#include "flat_stream.h"
 #include "topk.h"
 
 #include <algorithm>
@@ -696,11 +697,25 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         MfmaPlan ps, pf;
         // measured crossover (benchmarks/run_filter_k.sh): nq = 64: filter mode wins from k = 16;
         // nq = 1024 (one list per query and block): from k = 32
-        const int64_t filter_k = opt.mfma_filter_k > 0 ? opt.mfma_filter_k : (nq <= 128 ? 16 : 33);
+        // stream kernel (nq <= 16, lists in registers; benchmarks/run_stream_k.sh): up to 8 queries
+        // list mode holds up to k = 64 (nq 8, k 64: 2.60 ms against 2.68), 9..16 queries up to k ~ 16
+        // (nq 16, k 32: 3.24 ms against 2.85)
+        StreamPlan probe;
+        const bool stream_ok = stream_plan(n, nq, 1, dch, bf, false, 0, 1, &probe);
+        const int64_t filter_k = opt.mfma_filter_k > 0 ? opt.mfma_filter_k
+                                 : stream_ok           ? (nq > 8 ? 24 : 65)
+                                                       : (nq <= 128 ? 16 : 33);
         const bool filter = k >= filter_k && n >= opt.mfma_filter_min_rows &&
                             mfma_plan(std::max<long long>(1, n / FILTER_STEP), nq, j, bf, &ps) &&
                             mfma_plan_filter(n, nq, bf, cap, &pf);
+        // batches of up to 16 queries: the register-fed stream kernel (flat_stream.hip) takes the pass
+        // over all rows, in list mode or as the filter pass; sample pass and redo stay with the tile kernel
+        StreamPlan sp, sps;
+        const bool stream = stream_plan(n, nq, k, dch, bf, filter, cap, 1, &sp) &&
+                            (!filter || stream_plan(n, nq, j, dch, bf, false, 0, FILTER_STEP, &sps));
         int64_t need = nq * plan.nlists * k;
+        if (stream && !filter) need = std::max<int64_t>(need, nq * (int64_t)sp.nlists * k);
+        if (stream && filter) need = std::max<int64_t>(need, nq * (int64_t)sps.nlists * j);
         if (filter) need = std::max<int64_t>(need, std::max<int64_t>(nq * ps.nlists * j, nq * (int64_t)cap));
         rc = grow(h->ws_key, h->ws_key_cap, need);
         if (rc) return rc;
@@ -761,24 +776,33 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         const int ldw = ld * h->esz / 4;
         merge_fn_t mf = pick_merge(KS, h->metric);
         if (!filter) {
-            rc = mfma_launch(plan, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
-                             h->ws_qn, h->zero16, st);
+            if (stream)
+                rc = stream_launch(sp, h->x, (long long)n, dch, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                                   h->ws_qn, st);
+            else
+                rc = mfma_launch(plan, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                                 h->ws_qn, h->zero16, st);
             if (rc) return rc;
             if (h->prof) {
                 RAG_HIP(hipEventRecord(e1, st));
                 h->ev_used.emplace_back(e0, e1);
             }
-            mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.nlists, k, D_dev, I_dev,
-                                                       (long long)id_base, k, 0, nullptr);
+            mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, stream ? sp.nlists : plan.nlists, k, D_dev,
+                                                       I_dev, (long long)id_base, k, 0, nullptr);
             RAG_HIP(hipGetLastError());
             return RAG_OK;
         }
         // 1. sample pass (list mode over every FILTER_STEP-th row tile) -> j best per query -> threshold
         ps.tile_step = FILTER_STEP;
-        rc = mfma_launch(ps, Xw, (long long)n, ldw, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
-                         h->zero16, st);
+        if (stream)
+            rc = stream_launch(sps, h->x, (long long)n, dch, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                               h->ws_qn, st);
+        else
+            rc = mfma_launch(ps, Xw, (long long)n, ldw, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                             h->ws_qn, h->zero16, st);
         if (rc) return rc;
-        pick_merge(1, h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, ps.nlists, j, h->ws_sD,
+        pick_merge(1, h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id,
+                                                                        stream ? sps.nlists : ps.nlists, j, h->ws_sD,
                                                                         h->ws_sI, 0LL, j, 0, nullptr);
         make_floor_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, st>>>(h->ws_sD, h->ws_sI, nq, j, j - 1, h->metric, 0LL,
                                                                        h->ws_thr, h->ws_fi);
@@ -788,8 +812,12 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         int* nfail = h->ws_cnt + nq;
         int* failq = h->ws_cnt + nq + 1;
         RAG_HIP(hipMemsetAsync(h->ws_cnt, 0, (size_t)(nq + 1) * sizeof(int), st));
-        rc = mfma_launch(pf, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
-                         h->zero16, st, nullptr, h->ws_thr, counts);
+        if (stream)
+            rc = stream_launch(sp, h->x, (long long)n, dch, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                               h->ws_qn, st, nullptr, h->ws_thr, counts);
+        else
+            rc = mfma_launch(pf, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                             h->ws_qn, h->zero16, st, nullptr, h->ws_thr, counts);
         if (rc) return rc;
         if (h->prof) {
             RAG_HIP(hipEventRecord(e1, st));

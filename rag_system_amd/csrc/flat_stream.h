@@ -1,0 +1,32 @@
+// flat_stream.h -- internal interface of the register-fed small-batch kernel (flat_stream.hip)
+// used by flat.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rag {
+
+struct StreamPlan {
+    int G;          // query groups of 4 (the kernel serves nq <= 4*G queries)
+    int RG;         // row groups of 4 per wave tile
+    int KS;         // 64-entry register slots per top-k list (list mode)
+    bool bf16;      // rows and queries are bfloat16
+    bool filt;      // filter mode: fixed per-query thresholds + append buffers instead of lists
+    int cap;        // filter mode: entries per query in the append buffer
+    int tile_step;  // visit only wave tiles t*tile_step (sample pass; else 1)
+    int blocks;     // grid size = candidate lists written per query in list mode
+    int nlists;     // = blocks
+    size_t smem;
+};
+
+// false if this kernel does not serve the shape (nq > 16, k > 128, rows too long for the
+// LDS-resident queries): the caller uses the MFMA tile kernel or the scan kernel instead.
+bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt, int cap, int tile_step,
+                 StreamPlan* p);
+// X / Q: rows of dch 16-byte chunks (fp32: 4 values, bfloat16: 8 values per chunk; Q has nq rows
+// in the element type of X).  cand_*: list mode [nq][nlists][k], filter mode [nq][cap].
+// xnorm / qnorm only for L2.
+int stream_launch(const StreamPlan& p, const void* X, long long n, int dch, const void* Q, int nq, int k, int metric,
+                  float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st,
+                  const int* run_flag = nullptr, const float* thr_q = nullptr, unsigned int* counts = nullptr);
+
+}  // namespace rag

@@ -1,0 +1,434 @@
+// flat_stream.hip -- exact top-k of a small query batch (nq <= 16) over a row-major matrix, rows
+// streamed from HBM straight into MFMA operands (no LDS staging of the matrix).
+//
+// Replaces, for 3..16 queries per call, the same reference loop as flat.hip:
+// vector_storage.py:257-271 (faiss IndexFlat.search) / :159-195 (Python fallback), one call per
+// query in the reference; SURVEY.md section 8 row (a), batched by search_engine.search_faiss_batch.
+//
+// Why a third kernel: with <= 16 queries every matrix element is used by exactly one matrix
+// instruction, so the LDS tile ring of flat_mfma_kernel.h only adds latency (its load, LDS and MFMA
+// phases run in lock step: 3.1-3.6 ms per pass over 10M x 384 against the 2.2 ms the bytes cost),
+// while the scan kernel's per-query VALU work does not scale past two queries.  Here a wave loads
+// 4 rows x 256 B per instruction in exactly the operand layout of v_mfma_f32_4x4x1_16b_f32
+// (lane 4b+i = row i, 16-byte chunk b; benchmarks/membw_quad.hip: this pattern streams at
+// 7.0-7.1 TB/s like any other) and feeds each loaded register to the matrix core once per group of
+// 4 queries: block b of the instruction accumulates D_b[i][j] += x[row i][k_b] * q[query j][k_b],
+// 16 independent k slices at a time, 64 flops per cycle and SIMD -- 0.2 ms per 4 queries for
+// 10M x 384, hidden under the stream.  bfloat16 rows use v_mfma_f32_4x4x4_16b_bf16 the same way
+// (a lane's 8 values = 2 instructions).  A tile ends with a fold of the 16 k-slice partials over
+// lane bits 2..5 (DPP / permlane, no LDS): every lane then holds one (row, query) score.
+//
+// Numerics: fp32 products and accumulation inside the matrix core (each slice an fmaf chain in k
+// order, slices added in a fixed tree): within the 1e-5 bar of the float64 oracle, independent of
+// the launch shape.  Selection is exact (same lists / filter buffers as the other kernels).
+#include "common.h"
+#include "flat_stream.h"
+#include "topk.h"
+
+#include <algorithm>
+
+#ifndef RAG_STREAM_NB
+#define RAG_STREAM_NB 3  // segment buffers per wave: NB-1 segments in flight ahead of the one being multiplied
+#endif
+
+namespace rag {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ST_THREADS = 256;
+constexpr int ST_WAVES = ST_THREADS / 64;
+constexpr int NB = RAG_STREAM_NB;
+
+// Sum N = 4*RG per-lane values over lane bits 5..2 (the 16 k slices), halving the value count
+// at each step while it lasts: afterwards v[0] of lane l is the total of item (l >> (6-log2 N)).
+// Distances 32 and 16 fold a pair of registers with ONE v_permlane{32,16}_swap (the halves that
+// have to change lanes trade places) and one add -- no selects.
+template <int N, int HALF, int DIST>
+__device__ __forceinline__ void fold_slices(float (&v)[N], int lane) {
+    if constexpr (DIST >= 4) {
+        if constexpr (HALF >= 1) {
+            if constexpr (DIST >= 16) {
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) {
+                    const int a = __float_as_int(v[i]), c = __float_as_int(v[i + HALF]);
+                    if constexpr (DIST == 32) {
+                        const auto p = __builtin_amdgcn_permlane32_swap(a, c, false, false);
+                        v[i] = __int_as_float(p[0]) + __int_as_float(p[1]);
+                    } else {
+                        const auto p = __builtin_amdgcn_permlane16_swap(a, c, false, false);
+                        v[i] = __int_as_float(p[0]) + __int_as_float(p[1]);
+                    }
+                }
+            } else {
+                const bool upper = (lane & DIST) != 0;
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) {
+                    const float keep = upper ? v[i + HALF] : v[i];
+                    const float send = upper ? v[i] : v[i + HALF];
+                    v[i] = keep + xor_lane<DIST>(send);
+                }
+            }
+            fold_slices<N, HALF / 2, DIST / 2>(v, lane);
+        } else {
+            v[0] += xor_lane<DIST>(v[0]);
+            fold_slices<N, 0, DIST / 2>(v, lane);
+        }
+    }
+}
+
+// n >= 4*RG (the host plans the tile kernel for smaller shards): the last, partial wave tile is
+// the window [n - 4*RG, n) with the rows below the tile's own first row masked out.
+template <int G, int RG, int KS, int METRIC, bool BF, bool FILT>
+__global__ __launch_bounds__(ST_THREADS, (G * RG >= 8 ? 3 : 4)) void flat_stream_kernel(
+    const u32x4* __restrict__ X, long long n, int dch, const u32x4* __restrict__ Q, int nq, int k,
+    float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
+    const float* __restrict__ qnorm, long long tile_step, const int* __restrict__ run_flag,
+    const float* __restrict__ thr_q, unsigned int* __restrict__ counts, int cap) {
+    if (run_flag != nullptr && *run_flag == 0) return;  // uniform, before any barrier
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    u32x4* q_lds = reinterpret_cast<u32x4*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the address math below
+    const int b = lane >> 2, j = lane & 3;   // k slice (16-byte chunk within a 256-byte segment), query in group
+    const int dchp = ((dch + 16 * NB - 1) / (16 * NB)) * (16 * NB);  // whole segments, a multiple of NB of them
+
+    // queries: chunk c of query 4g+jj at q_lds[(g*dchp + c)*4 + jj] -> one lane-linear b128 read per
+    // (segment, group); missing queries and the chunks past the row end are zeros
+    for (int i = tid; i < G * dchp * 4; i += ST_THREADS) {
+        const int jj = i & 3, c = (i >> 2) % dchp, g = (i >> 2) / dchp;
+        const int q = 4 * g + jj;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q < nq && c < dch) v = Q[(long long)q * dch + c];
+        q_lds[i] = v;
+    }
+    __syncthreads();
+
+    constexpr int NL = FILT ? 1 : 4 * G;
+    using TK = WaveTopK<float, int, KS>;
+    TK tk[NL];
+    float thr_k[NL];
+    int thr_i[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+        tk[q].init();
+        thr_k[q] = Lowest<float>::v();
+        thr_i[q] = IdPad<int>::v();
+    }
+    float thr_lane[G], qn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int q = 4 * g + j;
+        thr_lane[g] = FILT ? (q < nq ? thr_q[q] : FLT_MAX) : Lowest<float>::v();
+        qn[g] = (METRIC == RAG_METRIC_L2 && q < nq) ? qnorm[q] : 0.f;
+    }
+
+    constexpr int N = 4 * RG;
+    constexpr int LOGN = Log2<N>::v;
+    const int item = (lane >> (6 - LOGN)) & (N - 1);
+    const bool rep = (lane & ((1 << (6 - LOGN)) - 1) & ~3) == 0;
+    constexpr long long TR = 4 * RG;
+    const long long W = (long long)gridDim.x * ST_WAVES;
+    const long long gw = (long long)blockIdx.x * ST_WAVES + wid;
+    const long long ntiles = ((n + TR - 1) / TR + tile_step - 1) / tile_step;
+    const long long trows = TR * tile_step;
+
+    // Addresses: wave-uniform 64-bit base (tile, segment, row group) + a per-lane 32-bit offset
+    // that never changes -> no vector address arithmetic in the loop.
+    const char* Xb = reinterpret_cast<const char*>(X);
+    const unsigned int voff = ((unsigned int)j * (unsigned int)dch + (unsigned int)b) * 16u;
+    const long long rg_bytes = 64LL * dch;  // 4 rows
+    const int nseg = dchp >> 4;             // 256-byte segments per row, padded to a multiple of NB
+
+    // Register ring of NB segment buffers with STATIC indices (a copy of a register that is still
+    // being loaded would wait for the load): step s multiplies buf[s % NB] after issuing the loads
+    // of step s + NB - 1 into the buffer step s - 1 left free.  Every tile takes nseg (a multiple
+    // of NB) steps, so a tile always starts at buf[0]; segments past the row end are zeros.
+    long long ti = gw;         // issue side: next (tile, segment) to load
+    int si = 0;
+    const char* isb = nullptr;  // base of tile ti
+    auto tile_base = [&](long long t) {
+        long long r0 = t * trows;
+        r0 = r0 < n - TR ? r0 : n - TR;
+        return Xb + r0 * dch * 16;
+    };
+    isb = tile_base(ti < ntiles ? ti : 0);
+    auto issue = [&](u32x4(&dst)[RG]) {
+        if (ti < ntiles) {
+            const int ci = si << 4;
+            const char* sb = isb + (long long)ci * 16;
+            if (ci + 16 <= dch) {
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+                    dst[rg] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sb + rg * rg_bytes + voff));
+            } else {  // the segment the rows end in (chunks past the end read as zeros), or padding
+                const bool okc = ci + b < dch;
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (okc) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sb + rg * rg_bytes + voff));
+                    dst[rg] = v;
+                }
+            }
+        }
+        if (++si == nseg) {
+            si = 0;
+            ti += W;
+            if (ti < ntiles) isb = tile_base(ti);
+        }
+    };
+    u32x4 buf[NB][RG];
+#pragma unroll
+    for (int p = 0; p < NB; ++p)
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) buf[p][rg] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p + 1 < NB; ++p) issue(buf[p]);
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto bf_half = [](const u32x4& v, int e) {
+        const unsigned int lo = v[2 * e], hi = v[2 * e + 1];
+        return s16x4{(short)(lo & 0xFFFFu), (short)(lo >> 16), (short)(hi & 0xFFFFu), (short)(hi >> 16)};
+    };
+    for (long long t = gw; t < ntiles; t += W) {
+        const long long row0 = t * trows;
+        const long long row0w = row0 < n - TR ? row0 : n - TR;
+        const long long row = row0w + item;
+        float xn = 0.f;
+        if (METRIC == RAG_METRIC_L2) xn = xnorm[row];  // in flight behind the tile's loads, used after them
+        f32x4 acc[G][RG];
+        for (int s0 = 0; s0 < nseg; s0 += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                issue(buf[(u + NB - 1) % NB]);
+                const u32x4(&xc)[RG] = buf[u];
+                u32x4 qv[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) qv[g] = q_lds[(g * dchp + (s0 + u) * 16) * 4 + lane];
+                // the first instruction of a tile starts from C = 0: the accumulators are never cleared
+                const bool first = u == 0 && s0 == 0;
+                if (!BF) {
+                    if (first) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int rg = 0; rg < RG; ++rg)
+                                acc[g][rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                                    __uint_as_float(xc[rg][0]), __uint_as_float(qv[g][0]), zero4, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int rg = 0; rg < RG; ++rg)
+                                acc[g][rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                                    __uint_as_float(xc[rg][0]), __uint_as_float(qv[g][0]), acc[g][rg], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int rg = 0; rg < RG; ++rg)
+                                acc[g][rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                                    __uint_as_float(xc[rg][e]), __uint_as_float(qv[g][e]), acc[g][rg], 0, 0, 0);
+                } else {
+                    if (first) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int rg = 0; rg < RG; ++rg)
+                                acc[g][rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(bf_half(xc[rg], 0), bf_half(qv[g], 0),
+                                                                                  zero4, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int rg = 0; rg < RG; ++rg)
+                                acc[g][rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(bf_half(xc[rg], 0), bf_half(qv[g], 0),
+                                                                                  acc[g][rg], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int rg = 0; rg < RG; ++rg)
+                            acc[g][rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(bf_half(xc[rg], 1), bf_half(qv[g], 1),
+                                                                              acc[g][rg], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- tile epilogue: fold the k slices, one (row, query) score per lane and group
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float v[N];
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[rg * 4 + i] = acc[g][rg][i];
+            fold_slices<N, N / 2, 32>(v, lane);
+            const float key = METRIC == RAG_METRIC_IP ? v[0] : (2.f * v[0] - xn) - qn[g];
+            const bool ok = rep && row >= row0 && 4 * g + j < nq && key >= thr_lane[g];
+            const unsigned long long m = __ballot(ok);
+            if (m != 0ULL) {
+                if (FILT) {
+                    if (ok) {
+                        const int q = 4 * g + j;
+                        const unsigned int slot = atomicAdd(&counts[q], 1u);
+                        if (slot < (unsigned int)cap) {
+                            const long long o = (long long)q * cap + slot;
+                            cand_key[o] = key;
+                            cand_id[o] = (int)row;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (m & (0x1111111111111111ULL << jj)) {
+                            const int q = FILT ? 0 : 4 * g + jj;  // static after unrolling
+                            wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], key, (int)row, ok && j == jj, lane);
+                            if (j == jj) thr_lane[g] = thr_k[q];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (FILT) return;
+    // ---- merge the block's four wave lists through LDS (over the query area), wave 0 writes one
+    // list per real query: cand[q][block][k]
+    __syncthreads();
+    float* mk = reinterpret_cast<float*>(smem_raw);
+    int* mi = reinterpret_cast<int*>(mk + (ST_WAVES - 1) * NL * KS * 64);
+    if (wid > 0) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int o = (((wid - 1) * NL + q) * KS + s) * 64 + lane;
+                mk[o] = tk[q].key[s];
+                mi[o] = tk[q].id[s];
+            }
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            if (q < nq) {
+                for (int w = 0; w < ST_WAVES - 1; ++w)
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const int o = ((w * NL + q) * KS + s) * 64 + lane;
+                        wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], mk[o], mi[o], true, lane);
+                    }
+                const long long base = ((long long)q * gridDim.x + blockIdx.x) * k;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int p = s * 64 + lane;
+                    if (p < k) {
+                        cand_key[base + p] = tk[q].key[s];
+                        cand_id[base + p] = tk[q].id[s];
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct Args {
+    const void *X, *Q;
+    long long n;
+    int dch, nq, k, metric;
+    float* cand_key;
+    int* cand_id;
+    const float *xnorm, *qnorm;
+    const int* run_flag;
+    const float* thr_q;
+    unsigned int* counts;
+    hipStream_t st;
+};
+
+template <int G, int RG, int KS, bool BF, bool FILT>
+int launch(const StreamPlan& p, const Args& a) {
+    auto fn = a.metric == RAG_METRIC_IP ? flat_stream_kernel<G, RG, KS, RAG_METRIC_IP, BF, FILT>
+                                        : flat_stream_kernel<G, RG, KS, RAG_METRIC_L2, BF, FILT>;
+    if (p.smem > 48 * 1024)
+        RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)p.smem));
+    fn<<<(unsigned)p.blocks, ST_THREADS, p.smem, a.st>>>(
+        reinterpret_cast<const u32x4*>(a.X), a.n, a.dch, reinterpret_cast<const u32x4*>(a.Q), a.nq, a.k, a.cand_key,
+        a.cand_id, a.xnorm, a.qnorm, (long long)p.tile_step, a.run_flag, a.thr_q, a.counts, p.cap);
+    RAG_HIP(hipGetLastError());
+    return RAG_OK;
+}
+
+template <int G, int RG, bool BF>
+int launch_mode(const StreamPlan& p, const Args& a) {
+    if (p.filt) return launch<G, RG, 1, BF, true>(p, a);
+    return p.KS == 1 ? launch<G, RG, 1, BF, false>(p, a) : launch<G, RG, 2, BF, false>(p, a);
+}
+
+template <int G, bool BF>
+int launch_rg(const StreamPlan& p, const Args& a) {
+    if constexpr (G < 4) {
+        if (p.RG == 4) return launch_mode<G, 4, BF>(p, a);
+    }
+    return launch_mode<G, 2, BF>(p, a);  // 4 query groups x 4 row groups of accumulators do not fit 3 waves per SIMD
+}
+
+template <bool BF>
+int launch_g(const StreamPlan& p, const Args& a) {
+    switch (p.G) {
+        case 1: return launch_rg<1, BF>(p, a);
+        case 2: return launch_rg<2, BF>(p, a);
+        default: return launch_rg<4, BF>(p, a);
+    }
+}
+
+}  // namespace
+
+bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt, int cap, int tile_step,
+                 StreamPlan* p) {
+    const Options& opt = options();
+    const long long max_nq = opt.stream_max_nq > 0 ? std::min<long long>(opt.stream_max_nq, 16) : 16;
+    if (opt.stream_max_nq < 0 || nq < 1 || nq > max_nq || n < 1) return false;
+    if (!filt && (k < 1 || k > 128)) return false;
+    if (n < 16) return false;  // a wave tile is up to 16 rows; tiny shards go to the tile kernel
+    p->G = nq <= 4 ? 1 : (nq <= 8 ? 2 : 4);
+    p->KS = k <= 64 ? 1 : 2;
+    p->bf16 = bf16;
+    p->filt = filt;
+    p->cap = cap;
+    p->tile_step = tile_step < 1 ? 1 : tile_step;
+    p->RG = opt.stream_rg == 2 || opt.stream_rg == 4 ? (int)opt.stream_rg : (p->G == 4 ? 2 : 4);
+    if (p->G == 4) p->RG = 2;
+    const int dchp = ((dch + 16 * NB - 1) / (16 * NB)) * (16 * NB);
+    const size_t qbytes = (size_t)p->G * dchp * 64;
+    const size_t mbytes = filt ? 0 : (size_t)(ST_WAVES - 1) * 4 * p->G * p->KS * 64 * 8;
+    p->smem = std::max(qbytes, mbytes);
+    if (p->smem > 64 * 1024) return false;  // long rows: the tile kernel streams its queries instead
+    const long long TR = 4 * p->RG;
+    const long long ntiles = ((n + TR - 1) / TR + p->tile_step - 1) / p->tile_step;
+    const long long bpc = opt.stream_bpc > 0 ? opt.stream_bpc : (p->G * p->RG >= 8 ? 3 : 4);  // = the kernel's launch bound
+    long long blocks = std::min<long long>((long long)num_cus() * bpc, (ntiles + ST_WAVES - 1) / ST_WAVES);
+    p->blocks = (int)std::max<long long>(blocks, 1);
+    p->nlists = p->blocks;
+    return true;
+}
+
+int stream_launch(const StreamPlan& p, const void* X, long long n, int dch, const void* Q, int nq, int k, int metric,
+                  float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st,
+                  const int* run_flag, const float* thr_q, unsigned int* counts) {
+    if (nq < 1 || nq > 4 * p.G) return fail(RAG_ERR_INVALID_ARG, "stream kernel: nq=%d beyond the planned %d", nq, 4 * p.G);
+    if (!p.filt && (k < 1 || k > 64 * p.KS)) return fail(RAG_ERR_INVALID_ARG, "stream kernel: k=%d beyond %d", k, 64 * p.KS);
+    if (p.filt && (thr_q == nullptr || counts == nullptr || p.cap < 1))
+        return fail(RAG_ERR_INVALID_ARG, "stream kernel: filter mode needs thresholds, counters and a capacity");
+    if (metric == RAG_METRIC_L2 && (xnorm == nullptr || qnorm == nullptr))
+        return fail(RAG_ERR_INVALID_ARG, "stream kernel: L2 needs row and query norms");
+    const Args a{X, Q, n, dch, nq, k, metric, cand_key, cand_id, xnorm, qnorm, run_flag, thr_q, counts, st};
+    return p.bf16 ? launch_g<true>(p, a) : launch_g<false>(p, a);
+}
+
+}  // namespace rag

@@ -92,6 +92,9 @@ int rag_set_option(const char* name, int64_t value) {
     else if (!std::strcmp(name, "mfma_stages")) o.mfma_stages = value;
     else if (!std::strcmp(name, "mfma_filter_k")) o.mfma_filter_k = value;
     else if (!std::strcmp(name, "mfma_filter_min_rows")) o.mfma_filter_min_rows = value;
+    else if (!std::strcmp(name, "stream_max_nq")) o.stream_max_nq = value;
+    else if (!std::strcmp(name, "stream_rg")) o.stream_rg = value;
+    else if (!std::strcmp(name, "stream_bpc")) o.stream_bpc = value;
     else return rag::fail(RAG_ERR_INVALID_ARG, "unknown option '%s'", name);
     return RAG_OK;
 }

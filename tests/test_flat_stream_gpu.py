@@ -1,0 +1,175 @@
+"""GPU parity tests of the register-fed small-batch kernel (csrc/flat_stream.hip): batches of
+3..16 queries (2..16 for bfloat16 rows), k <= 128, list mode and filter mode.
+
+Checked against the float64 oracle (oracle/dense.py, restating vector_storage.py:159-195 and the
+IndexFlat.search call at :257-271) to the fp32 bar of BASELINE.json (1e-5 relative, ids identical
+except near-ties), and against the tile kernel it replaces for these batch sizes.
+"""
+import numpy as np
+import pytest
+
+from oracle import dense as od
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+ATOL = 2e-6
+
+
+def _rand_unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+    return x
+
+
+def _scorer(X, Q, metric):
+    X64, Q64 = X.astype(np.float64), Q.astype(np.float64)
+
+    def f(qi, ids):
+        rows = X64[ids]
+        return rows @ Q64[qi] if metric == 0 else ((rows - Q64[qi]) ** 2).sum(axis=1)
+    return f
+
+
+def _opts(lib, **kw):
+    from rag_system_amd import _lib
+    for name, val in kw.items():
+        _lib.check(lib.rag_set_option(name.encode(), val))
+
+
+def _check(idx, X, Q, k, metric, storage):
+    rnd = od.bf16_round if storage == "bf16" else (lambda a: a)
+    Xr, Qr = rnd(X), rnd(Q)
+    D, I = idx.search(Q, k)
+    _, Ir, D64 = od.flat_search(Xr, Qr, k, metric)
+    od.check_topk(D, I, D64, Ir, RTOL, ATOL if metric == 0 else 4e-6, _scorer(Xr, Qr, metric))
+    return D, I
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d", [(1, 384), (7, 64), (300, 384), (4099, 768), (3001, 37), (20_011, 384), (1000, 20),
+                                 (513, 8), (2000, 1000), (50_003, 72)])
+def test_list_mode_matches_oracle(engine, n, d, metric, storage):
+    """d = 37, 20, 8, 72, 1000: rows that end inside a 256-byte segment; n = 1, 7, 513: ragged tiles."""
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(n * 11 + d + metric)
+    X = _rand_unit(rng, n, d)
+    if n > 100:
+        X[n // 2] = X[3]
+        X[n - 1] = X[3]
+    idx = faiss.IndexFlat(d, metric, storage=storage)
+    idx.add(X)
+    for nq, k in [(3, 10), (4, 1), (5, 64), (8, 33), (9, 100), (12, 128), (16, 10), (16, 65), (2, 10)]:
+        Q = _rand_unit(rng, nq, d)
+        Q[0] = X[min(3, n - 1)]
+        _check(idx, X, Q, k, metric, storage)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_stream_kernel_agrees_with_tile_kernel_and_tile_heights(engine, storage):
+    """Same ids as the MFMA tile kernel (stream_max_nq = -1) and for both wave-tile heights; the
+    scores differ only in summation order."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(17)
+    X = _rand_unit(rng, 30_011, 200)
+    idx = faiss.IndexFlat(200, 0, storage=storage)
+    idx.add(X)
+    try:
+        for nq, k in [(3, 10), (6, 50), (13, 100), (16, 20)]:
+            Q = _rand_unit(rng, nq, 200)
+            D0, I0 = _check(idx, X, Q, k, 0, storage)
+            for rg in (2, 4):
+                for bpc in (1, 3, 5):
+                    _opts(lib, stream_rg=rg, stream_bpc=bpc)
+                    D1, I1 = _check(idx, X, Q, k, 0, storage)
+                    assert np.array_equal(I0, I1), (nq, k, rg, bpc)
+                    assert np.allclose(D0, D1, rtol=1e-6, atol=1e-7)
+            _opts(lib, stream_rg=0, stream_bpc=0, stream_max_nq=-1)
+            D2, I2 = _check(idx, X, Q, k, 0, storage)
+            _opts(lib, stream_max_nq=0)
+            assert np.array_equal(I0, I2), (nq, k)
+            assert np.allclose(D0, D2, rtol=2e-6, atol=2e-7)
+    finally:
+        _opts(lib, stream_rg=0, stream_bpc=0, stream_max_nq=0)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_filter_mode_matches_oracle(engine, storage):
+    """Sample pass and filter pass by the stream kernel (redo by the tile kernel), forced on
+    small inputs, including row orders that defeat the 1-in-32 sample."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(777)
+    rnd = od.bf16_round if storage == "bf16" else (lambda a: a)
+    try:
+        _opts(lib, mfma_filter_k=1, mfma_filter_min_rows=1)
+        for metric in (0, 1):
+            for n, d in [(300, 64), (20_011, 384), (70_001, 72), (9_000, 37)]:
+                X = _rand_unit(rng, n, d)
+                X[n // 2] = X[3]
+                X[n - 1] = X[3]
+                idx = faiss.IndexFlat(d, metric, storage=storage)
+                idx.add(X)
+                for nq, k in [(3, 10), (5, 1), (8, 100), (16, 50), (11, 128)]:
+                    Q = _rand_unit(rng, nq, d)
+                    Q[0] = X[3]
+                    _check(idx, X, Q, k, metric, storage)
+        n, d, k = 40_000, 32, 20
+        Q = _rand_unit(rng, 12, d)
+        base = _rand_unit(rng, n, d) * 0.01
+        tile = np.arange(n) // 256
+        cases = {}
+        a = base.copy(); a[:] = a[0]
+        cases["all_equal"] = a
+        b = base.copy(); b[(tile % 32 == 0)] *= 100.0
+        cases["best_in_sample"] = b
+        c = base.copy(); c[(tile % 32 == 5)] *= 100.0
+        cases["best_outside_sample"] = c
+        e = base.copy(); e[:300] = Q[0] * 3.0
+        cases["ties_at_top"] = e
+        for rows in (8, 16):                      # the stream kernel samples every 32nd wave tile of 8 / 16 rows
+            wt = np.arange(n) // rows
+            f = base.copy(); f[(wt % 32 == 0)] *= 100.0
+            cases["best_in_sample_%d" % rows] = f
+            g = base.copy(); g[(wt % 32 == 5)] *= 100.0
+            cases["best_outside_sample_%d" % rows] = g
+        for name, X in cases.items():
+            idx = faiss.IndexFlat(d, 0, storage=storage)
+            idx.add(X)
+            Xr, Qr = rnd(X), rnd(Q)
+            D, I = idx.search(Q, k)
+            _, Ir, D64 = od.flat_search(Xr, Qr, k, 0)
+            od.check_topk(D, I, D64, Ir, RTOL, ATOL, _scorer(Xr, Qr, 0))
+            if name in ("all_equal", "ties_at_top"):
+                assert np.array_equal(I[0], Ir[0]), name
+    finally:
+        _opts(lib, mfma_filter_k=0, mfma_filter_min_rows=1 << 19)
+
+
+def test_default_thresholds_on_a_large_shard(engine):
+    """2M x 96 rows: k = 10 runs list mode, k = 100 filter mode by default; both exact, and the
+    ids do not depend on which kernel made the pass."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    n, d, seed = 2_000_000, 96, 99
+    idx = faiss.IndexFlat(d, 0)
+    idx._b.add_synthetic(n, seed, 0)
+    Q = od.synth_queries(5, 16, d)
+    Q[1] = od.synth_rows(seed, 1_234_567, 1, d)[0]
+    for nq, k in [(16, 10), (16, 100), (4, 100), (7, 64)]:
+        D, I = idx.search(Q[:nq], k)
+        _, Ir, D64 = od.flat_search_synth(seed, 0, n, d, Q[:nq], k)
+
+        def scorer(qi, ids):
+            rows = np.stack([od.synth_rows(seed, int(i), 1, d)[0] for i in ids])
+            return rows.astype(np.float64) @ Q[qi].astype(np.float64)
+        od.check_topk(D, I, D64, Ir, RTOL, ATOL, scorer)
+        assert I[1, 0] == 1_234_567
+        try:
+            _opts(lib, stream_max_nq=-1)
+            D2, I2 = idx.search(Q[:nq], k)
+        finally:
+            _opts(lib, stream_max_nq=0)
+        assert np.array_equal(I, I2), (nq, k)
