@@ -702,7 +702,15 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         // (nq 16, k 32: 3.24 ms against 2.85)
         StreamPlan probe;
         const bool stream_ok = stream_plan(n, nq, 1, dch, bf, false, 0, 1, &probe);
+        // 17..64 queries on a large shard: the 16x16 register-fed kernel (flat_wide.hip), which only
+        // has sample and filter passes -> filter mode for every k
+        WidePlan wp;
+        // from 9 queries: 10M x 384, nq 16: 2.57-2.67 ms against 2.76 for the stream kernel (k = 100: 2.67 / 3.26)
+        const int64_t wide_min_nq = opt.wide_min_nq > 0 ? opt.wide_min_nq : 9;
+        const bool wide = nq >= wide_min_nq && opt.mfma_filter_k <= 1 && n >= opt.mfma_filter_min_rows &&
+                          wide_plan(n, nq, dch, bf, j, cap, FILTER_STEP, &wp);
         const int64_t filter_k = opt.mfma_filter_k > 0 ? opt.mfma_filter_k
+                                 : wide                ? 1
                                  : stream_ok           ? (nq > 8 ? 24 : 65)
                                                        : (nq <= 128 ? 16 : 33);
         const bool filter = k >= filter_k && n >= opt.mfma_filter_min_rows &&
@@ -711,11 +719,12 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         // batches of up to 16 queries: the register-fed stream kernel (flat_stream.hip) takes the pass
         // over all rows, in list mode or as the filter pass; sample pass and redo stay with the tile kernel
         StreamPlan sp, sps;
-        const bool stream = stream_plan(n, nq, k, dch, bf, filter, cap, 1, &sp) &&
+        const bool stream = !wide && stream_plan(n, nq, k, dch, bf, filter, cap, 1, &sp) &&
                             (!filter || stream_plan(n, nq, j, dch, bf, false, 0, FILTER_STEP, &sps));
         int64_t need = nq * plan.nlists * k;
         if (stream && !filter) need = std::max<int64_t>(need, nq * (int64_t)sp.nlists * k);
         if (stream && filter) need = std::max<int64_t>(need, nq * (int64_t)sps.nlists * j);
+        if (wide && filter) need = std::max<int64_t>(need, nq * (int64_t)wp.wpad);
         if (filter) need = std::max<int64_t>(need, std::max<int64_t>(nq * ps.nlists * j, nq * (int64_t)cap));
         rc = grow(h->ws_key, h->ws_key_cap, need);
         if (rc) return rc;
@@ -794,7 +803,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         }
         // 1. sample pass (list mode over every FILTER_STEP-th row tile) -> j best per query -> threshold
         ps.tile_step = FILTER_STEP;
-        if (stream)
+        if (wide)
+            rc = wide_sample(wp, h->x, (long long)n, dch, Qw, (int)nq, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
+                             st);
+        else if (stream)
             rc = stream_launch(sps, h->x, (long long)n, dch, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm,
                                h->ws_qn, st);
         else
@@ -802,7 +814,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                              h->ws_qn, h->zero16, st);
         if (rc) return rc;
         pick_merge(1, h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id,
-                                                                        stream ? sps.nlists : ps.nlists, j, h->ws_sD,
+                                                                        wide     ? wp.wpad / j
+                                                                        : stream ? sps.nlists
+                                                                                 : ps.nlists,
+                                                                        j, h->ws_sD,
                                                                         h->ws_sI, 0LL, j, 0, nullptr);
         make_floor_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, st>>>(h->ws_sD, h->ws_sI, nq, j, j - 1, h->metric, 0LL,
                                                                        h->ws_thr, h->ws_fi);
@@ -812,7 +827,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         int* nfail = h->ws_cnt + nq;
         int* failq = h->ws_cnt + nq + 1;
         RAG_HIP(hipMemsetAsync(h->ws_cnt, 0, (size_t)(nq + 1) * sizeof(int), st));
-        if (stream)
+        if (wide)
+            rc = wide_filter(wp, h->x, (long long)n, dch, Qw, (int)nq, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
+                             h->ws_thr, counts, st);
+        else if (stream)
             rc = stream_launch(sp, h->x, (long long)n, dch, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
                                h->ws_qn, st, nullptr, h->ws_thr, counts);
         else

@@ -29,4 +29,25 @@ int stream_launch(const StreamPlan& p, const void* X, long long n, int dch, cons
                   float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st,
                   const int* run_flag = nullptr, const float* thr_q = nullptr, unsigned int* counts = nullptr);
 
+// ---- flat_wide.hip: 17..64 queries, 16x16 MFMA fed from registers, sample + filter passes only
+struct WidePlan {
+    int NT;           // query tiles of 16
+    bool bf16;
+    int cap;          // filter pass: entries per query in the append buffer
+    int sample_step;  // sample pass: every sample_step-th 16-row tile
+    int blocks, wpb;  // grid, waves per block
+    int wpad;         // sample pass output entries per query (>= blocks*wpb, a multiple of j)
+    size_t smem;
+};
+// false if the kernel does not serve the shape (nq > 64, fewer than 16 rows, queries beyond the LDS).
+// j = sample entries wanted per query (the caller's merge reads wpad/j lists of j).
+bool wide_plan(long long n, long long nq, int dch, bool bf16, int j, int cap, int sample_step, WidePlan* p);
+// cand_*: [nq][wpad] (best score of every wave over its sampled tiles, pads = (-FLT_MAX, INT_MAX))
+int wide_sample(const WidePlan& p, const void* X, long long n, int dch, const void* Q, int nq, int metric,
+                float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st);
+// cand_*: [nq][cap]; counts zeroed by the caller
+int wide_filter(const WidePlan& p, const void* X, long long n, int dch, const void* Q, int nq, int metric,
+                float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, const float* thr_q,
+                unsigned int* counts, hipStream_t st);
+
 }  // namespace rag

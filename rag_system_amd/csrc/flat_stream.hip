@@ -146,37 +146,36 @@ __global__ __launch_bounds__(ST_THREADS, (G * RG >= 8 ? 3 : 4)) void flat_stream
     // being loaded would wait for the load): step s multiplies buf[s % NB] after issuing the loads
     // of step s + NB - 1 into the buffer step s - 1 left free.  Every tile takes nseg (a multiple
     // of NB) steps, so a tile always starts at buf[0]; segments past the row end are zeros.
+    // EVERY path through issue() issues exactly RG loads (past the last tile: the last tile again;
+    // past the row end: the row's last chunk, zeroed when it is used), so the compiler can count
+    // outstanding loads (s_waitcnt vmcnt(N)) instead of draining them.
     long long ti = gw;         // issue side: next (tile, segment) to load
     int si = 0;
-    const char* isb = nullptr;  // base of tile ti
     auto tile_base = [&](long long t) {
+        t = t < ntiles ? t : ntiles - 1;
         long long r0 = t * trows;
         r0 = r0 < n - TR ? r0 : n - TR;
         return Xb + r0 * dch * 16;
     };
-    isb = tile_base(ti < ntiles ? ti : 0);
+    const char* isb = tile_base(ti);  // base of tile ti
     auto issue = [&](u32x4(&dst)[RG]) {
-        if (ti < ntiles) {
-            const int ci = si << 4;
+        const int ci = si << 4;
+        if (ci + 16 <= dch) {
             const char* sb = isb + (long long)ci * 16;
-            if (ci + 16 <= dch) {
 #pragma unroll
-                for (int rg = 0; rg < RG; ++rg)
-                    dst[rg] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sb + rg * rg_bytes + voff));
-            } else {  // the segment the rows end in (chunks past the end read as zeros), or padding
-                const bool okc = ci + b < dch;
+            for (int rg = 0; rg < RG; ++rg)
+                dst[rg] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sb + rg * rg_bytes + voff));
+        } else {  // the segment the rows end in, or padding
+            const int c = ci + b < dch ? ci + b : dch - 1;
+            const unsigned int vo = ((unsigned int)j * (unsigned int)dch + (unsigned int)c) * 16u;
 #pragma unroll
-                for (int rg = 0; rg < RG; ++rg) {
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (okc) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sb + rg * rg_bytes + voff));
-                    dst[rg] = v;
-                }
-            }
+            for (int rg = 0; rg < RG; ++rg)
+                dst[rg] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(isb + rg * rg_bytes + vo));
         }
         if (++si == nseg) {
             si = 0;
             ti += W;
-            if (ti < ntiles) isb = tile_base(ti);
+            isb = tile_base(ti);
         }
     };
     u32x4 buf[NB][RG];
@@ -203,7 +202,15 @@ __global__ __launch_bounds__(ST_THREADS, (G * RG >= 8 ? 3 : 4)) void flat_stream
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 issue(buf[(u + NB - 1) % NB]);
-                const u32x4(&xc)[RG] = buf[u];
+                u32x4 xc[RG];
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) xc[rg] = buf[u][rg];
+                if (((s0 + u) << 4) + 16 > dch) {  // uniform: the segment the rows end in, or padding
+                    if (((s0 + u) << 4) + b >= dch) {  // chunks past the row end count as zeros
+#pragma unroll
+                        for (int rg = 0; rg < RG; ++rg) xc[rg] = u32x4{0u, 0u, 0u, 0u};
+                    }
+                }
                 u32x4 qv[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) qv[g] = q_lds[(g * dchp + (s0 + u) * 16) * 4 + lane];

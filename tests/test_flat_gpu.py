@@ -448,4 +448,12 @@ def test_mfma_filter_mode_default_thresholds(engine):
         D2, I2 = idx.search(Q, 50)
     finally:
         _with_options(lib, {"mfma_filter_k": 0})
-    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    # 40 queries: the default pass is the 16x16 register-fed kernel (flat_wide.hip), the forced
+    # list mode the LDS tile kernel -> same ids, scores equal up to the summation order
+    assert np.array_equal(I, I2) and np.allclose(D, D2, rtol=2e-6, atol=2e-7)
+    try:
+        _with_options(lib, {"wide_max_nq": -1})          # tile kernel in filter mode: bit-identical to its list mode
+        D3, I3 = idx.search(Q, 50)
+    finally:
+        _with_options(lib, {"wide_max_nq": 0})
+    assert np.array_equal(I2, I3) and np.array_equal(D2, D3)
