@@ -31,7 +31,7 @@ def newest(pattern):
 
 
 for src, dst in (("nq1_stats", "bench_nq1"), ("nq1024_stats", "bench_nq1024"), ("c3_stats", "bench_c3_bf16_nq1024_k100"),
-                 ("hyb_stats", "bench_hybrid_1m")):
+                 ("hyb_stats", "bench_hybrid_1m"), ("nq4_stats", "bench_nq4"), ("nq64_stats", "bench_nq64")):
     shutil.copy(newest(P + src + "/*/*_kernel_stats.csv"), "profiles/%s_%s_kernel_stats.csv" % (tag, dst))
 
 name, f = dominant(ld("nq1_fetch"))
@@ -47,7 +47,9 @@ json.dump({"rows": 10000000, "dim": 384, "nq": 1, "storage": "f32", "hbm_bytes_p
 
 out = {}
 for key, names in (("f32_nq1024_k10", ("nq1024_sq", "nq1024_grbm", "nq1024_fetch")),
-                   ("bf16_768_nq1024_k100_filter_mode", ("c3_sq", "c3_grbm"))):
+                   ("bf16_768_nq1024_k100_filter_mode", ("c3_sq", "c3_grbm")),
+                   ("f32_nq4_k10_stream_kernel", ("nq4_sq", "nq4_grbm", "nq4_fetch")),
+                   ("f32_nq64_k10_wide_kernel_filter_pass", ("nq64_sq", "nq64_grbm", "nq64_fetch"))):
     d = {}
     for n in names:
         kname, cs = dominant(ld(n), "SQ_WAVE_CYCLES" if n.endswith("_sq") else None)
