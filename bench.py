@@ -246,7 +246,17 @@ def main():
             ach = flops / (avg_scan_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": ach / mfma_peak, "traffic": None}
-        roof.update({"kernel": "flat_scan_kernel" if nq < 5 else "flat_mfma_kernel", "avg_launch_ms": avg_scan_ms, "launches": n_launch,
+        # which kernel made the timed pass (the engine's dispatch, csrc/flat.hip search_device; the
+        # rocprofv3 summaries under profiles/ show the same names)
+        if k > 128:
+            kname = "flat_scan_kernel" if nq < (2 if bf else 3) else "flat_scan_kernel (pairs)"
+        elif nq <= 8 or (nq <= 16 and n_local < (1 << 19)):
+            kname = "flat_stream_kernel"
+        elif nq <= 64 and n_local >= (1 << 19):
+            kname = "flat_wide_kernel (sample + filter passes)"
+        else:
+            kname = "flat_mfma_kernel"
+        roof.update({"kernel": kname, "avg_launch_ms": avg_scan_ms, "launches": n_launch,
                      "algorithmic_bytes_per_launch": bytes_per_launch})
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1:

@@ -43,7 +43,7 @@ json.dump({"kernel": name, "FETCH_SIZE_KiB_units": f["FETCH_SIZE"], "WRITE_SIZE_
 hbm = f["FETCH_SIZE"]["mean"] * 1024 * 2
 json.dump({"rows": 10000000, "dim": 384, "nq": 1, "storage": "f32", "hbm_bytes_per_launch": hbm,
            "source": "profiles/%s_bench_nq1_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE (own pass), KiB units x2 gfx950 "
-                     "correction, mean over the timed scan launches" % tag}, open("profiles/traffic.json", "w"), indent=1)
+                     "correction, mean over the timed launches of the batch-1 kernel (flat_stream_kernel)" % tag}, open("profiles/traffic.json", "w"), indent=1)
 
 out = {}
 for key, names in (("f32_nq1024_k10", ("nq1024_sq", "nq1024_grbm", "nq1024_fetch")),

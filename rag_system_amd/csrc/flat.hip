@@ -682,7 +682,15 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     // batches from 3 queries (fp32 rows; 2 for bfloat16 rows) take the MFMA kernel: measured on
     // 10M rows, fp32 nq=2 scan 2.35 ms vs MFMA 3.1 ms, nq=3 4.6 vs 3.2; bf16 nq=2 2.61 vs 2.54
     const int64_t mfma_min_nq = opt.mfma_min_nq > 0 ? opt.mfma_min_nq : (bf ? 2 : 3);
-    if (nq >= mfma_min_nq && nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan)) {
+    // One or two queries, k <= 128: the stream kernel (flat_stream.hip) where it applies -- it reads
+    // the rows a little faster than the scan kernel below (10M x 384 fp32, nq = 1: 2.171 against
+    // 2.19-2.26 ms per pass; 10M x 768 bf16: 2.164 against 2.28; k = 100 through filter mode 2.35
+    // against 2.41-2.46 ms per step; benchmarks/run_nq1_stream.sh).  An explicit "mfma_min_nq"
+    // keeps such batches on the scan kernel.
+    StreamPlan small_probe;
+    const bool small_stream = opt.mfma_min_nq <= 0 && nq < mfma_min_nq && k <= 128 &&
+                              stream_plan(n, nq, 1, dch, bf, false, 0, 1, &small_probe);
+    if ((nq >= mfma_min_nq || small_stream) && nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan)) {
         // Filter mode for larger k on large shards: a 1/FILTER_STEP sample of the row tiles gives
         // each query a threshold (its j-th best sample score), one pass appends every row at or
         // above it, and the top-k of the few hundred appended rows is the exact result.  With

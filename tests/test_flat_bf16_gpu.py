@@ -72,7 +72,12 @@ def test_storage_rounds_to_nearest_even_and_reconstructs(engine):
 @pytest.mark.parametrize("metric", [0, 1])
 @pytest.mark.parametrize("n,d", [(1, 384), (7, 768), (1000, 384), (4099, 768), (3001, 37), (257, 8),
                                  (50_003, 384), (300, 2050)])
-def test_scan_matches_oracle_on_rounded_operands(engine, n, d, metric):
+@pytest.mark.parametrize("kernel", ["default", "scan"])
+def test_scan_matches_oracle_on_rounded_operands(engine, n, d, metric, kernel):
+    """kernel = "scan": every batch on the GEMV scan kernel ("mfma_min_nq" = 1000); by default
+    k <= 128 goes to the stream kernel."""
+    from rag_system_amd import _lib
+    lib = _lib.engine()
     rng = np.random.default_rng(n * 13 + d)
     X = _rand_unit(rng, n, d)
     if n > 100:
@@ -80,10 +85,15 @@ def test_scan_matches_oracle_on_rounded_operands(engine, n, d, metric):
         X[n - 1] = X[3]
     idx = _index(d, metric)
     idx.add(X)
-    for nq, k in [(1, 10), (2, 30), (3, 1), (4, 100), (1, 256), (2, 300)]:
-        Q = _rand_unit(rng, nq, d)
-        Q[0] = X[min(3, n - 1)]
-        _check(idx, X, Q, k, metric)
+    try:
+        if kernel == "scan":
+            _lib.check(lib.rag_set_option(b"mfma_min_nq", 1000))
+        for nq, k in [(1, 10), (2, 30), (3, 1), (4, 100), (1, 256), (2, 300)]:
+            Q = _rand_unit(rng, nq, d)
+            Q[0] = X[min(3, n - 1)]
+            _check(idx, X, Q, k, metric, atol=ATOL if (metric == 0 or kernel == "scan") else 4e-6)
+    finally:
+        lib.rag_set_option(b"mfma_min_nq", 0)
 
 
 @pytest.mark.parametrize("metric", [0, 1])

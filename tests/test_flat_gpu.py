@@ -62,15 +62,25 @@ def test_synthetic_rows_bit_identical(engine):
 @pytest.mark.parametrize("metric", [0, 1])
 @pytest.mark.parametrize("n,d", [(1, 384), (7, 384), (1000, 384), (4099, 768), (3001, 37), (257, 4),
                                  (50_003, 384), (1025, 1024), (300, 2050)])
-def test_search_matches_oracle(engine, n, d, metric):
+@pytest.mark.parametrize("kernel", ["default", "scan"])
+def test_search_matches_oracle(engine, n, d, metric, kernel):
+    """kernel = "scan": "mfma_min_nq" = 1000 keeps every batch on the GEMV scan kernel (by default
+    it serves k > 128, long rows and shards under 16 rows; smaller k goes to the stream kernel)."""
+    from rag_system_amd import _lib
+    lib = _lib.engine()
     rng = np.random.default_rng(n * 31 + d)
     X = _rand_unit(rng, n, d)
     idx = _index(d, metric)
     idx.add(X)
     assert idx.ntotal == n
-    for nq, k in [(1, 10), (2, 30), (3, 1), (5, 90), (19, 10), (1, 100), (4, 200), (1, 256)]:
-        Q = _rand_unit(rng, nq, d)
-        _check(idx, X, Q, k, metric)
+    try:
+        if kernel == "scan":
+            _lib.check(lib.rag_set_option(b"mfma_min_nq", 1000))
+        for nq, k in [(1, 10), (2, 30), (3, 1), (5, 90), (19, 10), (1, 100), (4, 200), (1, 256)]:
+            Q = _rand_unit(rng, nq, d)
+            _check(idx, X, Q, k, metric)
+    finally:
+        lib.rag_set_option(b"mfma_min_nq", 0)
 
 
 def test_unnormalised_rows_and_large_magnitudes(engine):
@@ -183,6 +193,7 @@ def test_results_independent_of_launch_shape(engine):
     Q = _rand_unit(rng, 3, 384)
     idx = _index(384)
     idx.add(X)
+    _lib.check(lib.rag_set_option(b"mfma_min_nq", 1000))   # the scan kernel, whose knobs these are
     D0, I0 = idx.search(Q, 30)
     try:
         for name, val in [("scan_blocks", 3), ("scan_blocks", 4096), ("scan_nt", 0), ("scan_rows", 2), ("scan_rows", 8)]:
@@ -200,6 +211,7 @@ def test_results_independent_of_launch_shape(engine):
         lib.rag_set_option(b"scan_blocks", 0)
         lib.rag_set_option(b"scan_nt", 1)
         lib.rag_set_option(b"scan_rows", 0)
+        lib.rag_set_option(b"mfma_min_nq", 0)
 
 
 def test_sharded_search_and_device_merge(engine):
