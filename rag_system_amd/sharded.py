@@ -73,6 +73,14 @@ class ShardedFlatSearcher:
             self.out_packed = torch.zeros(words, dtype=torch.int64, device=device)
             self.I_out = self.out_packed[:m].view(nq, k)
             self.D_out = self.out_packed[m:].view(torch.float32)[:m].view(nq, k)
+            # gloo with GPU tensors (the one-GPU functional rehearsal of bench.py; RCCL is the real
+            # transport): gloo's own device path stalled every other launch with several ranks on one
+            # card, so the packed lists are staged through host memory there
+            self._stage = (torch.device(device).type == "cuda" and dist.is_initialized()
+                           and dist.get_backend(group) == "gloo")
+            if self._stage:
+                self._h_pack = torch.zeros(words, dtype=torch.int64)
+                self._h_all = torch.zeros((self.world, words), dtype=torch.int64)
         else:
             self.out_packed, self.D_out, self.I_out = self._pack, self.D_loc, self.I_loc
 
@@ -88,6 +96,11 @@ class ShardedFlatSearcher:
         on the current stream for GPU tensors)."""
         self.local_search(q, self.k, self.D_loc, self.I_loc)
         if self.world > 1:
-            self._dist.all_gather_into_tensor(self._pack_all.view(-1), self._pack, group=self.group)
+            if self._stage:
+                self._h_pack.copy_(self._pack)        # ordered behind the local search on the current stream
+                self._dist.all_gather_into_tensor(self._h_all.view(-1), self._h_pack, group=self.group)
+                self._pack_all.copy_(self._h_all)
+            else:
+                self._dist.all_gather_into_tensor(self._pack_all.view(-1), self._pack, group=self.group)
             self.merge(self.metric, self.D_all, self.I_all, self.D_out, self.I_out)
         return self.D_out, self.I_out
