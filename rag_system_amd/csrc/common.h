@@ -35,6 +35,7 @@ struct Options {
     int64_t wide_max_nq = 0;    // batches up to this size take the 16x16 register-fed kernel (0 = auto: 64; -1 = never)
     int64_t wide_min_nq = 0;    // ... from this size (0 = auto: 9; smaller batches and small shards stay with the stream kernel)
     int64_t wide_wpb = 0;       // waves per block of that kernel (0 = auto by LDS use)
+    int64_t sparse_topk_lists = 0;  // 1: BM25 / TF-IDF top-k always by the list kernels (no threshold path)
 };
 Options& options();
 

@@ -62,7 +62,9 @@ __global__ void tfidf_term_kernel(const int* __restrict__ row, const double* __r
 template <int KS>
 __global__ __launch_bounds__(TK_THREADS) void dense_topk_kernel(const double* __restrict__ score, long long n,
                                                                 int k, double* __restrict__ cand_key,
-                                                                int* __restrict__ cand_id) {
+                                                                int* __restrict__ cand_id,
+                                                                const int* __restrict__ run_flag) {
+    if (run_flag != nullptr && *run_flag == 0) return;  // threshold path succeeded (uniform)
     __shared__ double mk[(TK_WAVES - 1) * KS * 64];
     __shared__ int mi[(TK_WAVES - 1) * KS * 64];
     // contiguous span per block so that in-wave ids ascend
@@ -96,7 +98,9 @@ template <int KS>
 __global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const double* __restrict__ cand_key,
                                                                          const int* __restrict__ cand_id,
                                                                          int nlists, int k, double* __restrict__ D,
-                                                                         long long* __restrict__ I) {
+                                                                         long long* __restrict__ I,
+                                                                         const int* __restrict__ run_flag) {
+    if (run_flag != nullptr && *run_flag == 0) return;
     __shared__ double mk[(MERGE_WAVES - 1) * KS * 64];
     __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
     WaveTopK<double, int, KS> tk;
@@ -129,6 +133,197 @@ __global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const d
                 I[p] = pad ? -1LL : (long long)tk.id[s];
             }
         }
+    }
+}
+
+// ---- threshold path of the dense top-k (large score vectors) -----------------------------------
+// Sorted inserts cost ~0.3-0.5 us each and every wave of dense_topk_kernel has to fill its own
+// k-list first, so that path takes 80-160 us for a million scores although reading them takes
+// 5 us.  Here: (1) SPANS = 1024 waves take the maximum of one contiguous span each; (2) the k-th
+// largest span maximum is a threshold T with at least k scores >= T by construction (k spans
+// hold one each) and, for scores in no particular order, few more than k; (3) every score > T is
+// appended to a buffer; (4) one block takes the exact best min(k, count) of the buffer and, when
+// fewer than k scores are strictly greater, completes the list with the lowest-numbered rows
+// scoring exactly T (ties rank by ascending row: the result is the stable descending sort the
+// reference takes, vector_storage.py:180).  A buffer overflow (scores sorted by row number, say)
+// sets a flag and the list kernels above run instead; they return at once when the flag is clear.
+constexpr int SPANS = 1024;
+constexpr int THR_CAP = 8192;
+
+__global__ __launch_bounds__(256) void span_max_kernel(const double* __restrict__ score, long long n,
+                                                       double* __restrict__ wmax) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long per = (n + SPANS - 1) / SPANS;
+    const long long lo = w * per, hi = lo + per < n ? lo + per : n;
+    double m = -DBL_MAX;
+    for (long long i = lo + lane; i < hi; i += 64) {
+        const double v = score[i];
+        m = v > m ? v : m;  // NaN never wins
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if (lane == 0) wmax[w] = m;
+}
+
+// One block of SPANS threads: bitonic sort (descending) of the span maxima in LDS, T = k-th largest.
+__global__ __launch_bounds__(SPANS) void kth_span_max_kernel(const double* __restrict__ wmax, int k,
+                                                             double* __restrict__ thr, int* __restrict__ counters) {
+    __shared__ double v[SPANS];
+    const int t = threadIdx.x;
+    v[t] = wmax[t];
+    if (t < 3) counters[t] = 0;  // [0] scores > T appended, [1] overflow flag, [2] rows scoring exactly T
+    __syncthreads();
+    for (int size = 2; size <= SPANS; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int p = t ^ stride;
+            if (p > t) {
+                const bool desc = (t & size) == 0;
+                const double a = v[t], b = v[p];
+                if (desc ? a < b : a > b) {
+                    v[t] = b;
+                    v[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (t == 0) thr[0] = v[k - 1];
+}
+
+__global__ __launch_bounds__(256) void compact_gt_kernel(const double* __restrict__ score, long long n,
+                                                         const double* __restrict__ thr, double* __restrict__ buf_key,
+                                                         int* __restrict__ buf_id, int* __restrict__ eq_id,
+                                                         int* __restrict__ counters) {
+    const double T = thr[0];
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // whole waves iterate together (the ballot below needs every lane)
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long rounds = (n + stride - 1) / stride;
+    for (long long r = 0; r < rounds; ++r) {
+        const long long i = first + r * stride;
+        const double v = i < n ? score[i] : -DBL_MAX;
+        const bool take = i < n && v > T;
+        const unsigned long long m = __ballot(take);
+        if (m != 0ULL) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counters[0], __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (take) {
+                const int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+                if (slot < THR_CAP) {
+                    buf_key[slot] = v;
+                    buf_id[slot] = (int)i;
+                }
+            }
+        }
+        // rows scoring exactly T: remembered while they are few (when they are many, the first
+        // k of them are found by a short scan from row 0)
+        const bool eq = i < n && v == T;
+        const unsigned long long me = __ballot(eq);
+        if (me != 0ULL) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counters[2], __popcll(me));
+            base = __shfl(base, 0, 64);
+            if (eq) {
+                const int slot = base + __popcll(me & ((1ULL << lane) - 1ULL));
+                if (slot < THR_CAP) eq_id[slot] = (int)i;
+            }
+        }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(MERGE_THREADS) void select_fill_kernel(const double* __restrict__ score, long long n,
+                                                                    const double* __restrict__ thr,
+                                                                    const double* __restrict__ buf_key,
+                                                                    const int* __restrict__ buf_id,
+                                                                    const int* __restrict__ eq_id,
+                                                                    int* __restrict__ counters, int k,
+                                                                    double* __restrict__ D, long long* __restrict__ I) {
+    __shared__ double mk[(MERGE_WAVES - 1) * KS * 64];
+    __shared__ int mi[(MERGE_WAVES - 1) * KS * 64];
+    __shared__ int wcount[MERGE_WAVES];
+    __shared__ int filled;
+    const int cnt = counters[0];
+    if (cnt > THR_CAP) {  // uniform: the list kernels take over
+        if (threadIdx.x == 0) counters[1] = 1;
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    WaveTopK<double, int, KS> tk;
+    block_merge<double, int, KS, MERGE_WAVES>(
+        [&](long long c, double& key, int& id) {
+            key = buf_key[c];
+            id = buf_id[c];
+            return true;
+        },
+        (long long)cnt, k, tk, mk, mi);
+    const int have = cnt < k ? cnt : k;
+    if (tid < 64) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int p = s * 64 + lane;
+            if (p < have) {
+                D[p] = tk.key[s];
+                I[p] = (long long)tk.id[s];
+            }
+        }
+    }
+    if (have == k) return;
+    // complete with the lowest-numbered rows scoring exactly T (at least k - have of them exist)
+    const double T = thr[0];
+    const int ceq = counters[2];
+    if (ceq <= THR_CAP) {  // few such rows: all remembered; the smallest row numbers = the best keys -row
+        const int need = k - have;
+        __syncthreads();   // the scratch of the first selection is free
+        WaveTopK<double, int, KS> te;
+        block_merge<double, int, KS, MERGE_WAVES>(
+            [&](long long c, double& key, int& id) {
+                id = eq_id[c];
+                key = -(double)id;
+                return true;
+            },
+            (long long)ceq, need, te, mk, mi);
+        if (tid < 64) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s * 64 + lane;
+                if (p < need && p < ceq) {
+                    D[have + p] = T;
+                    I[have + p] = (long long)te.id[s];
+                }
+            }
+        }
+        return;
+    }
+    if (tid == 0) filled = have;
+    __syncthreads();
+    for (long long base = 0; base < n; base += MERGE_THREADS) {
+        const long long i = base + tid;
+        const bool eq = i < n && score[i] == T;
+        const unsigned long long m = __ballot(eq);
+        if (lane == 0) wcount[wid] = __popcll(m);
+        __syncthreads();
+        int before = filled;
+        for (int w = 0; w < wid; ++w) before += wcount[w];
+        int total = 0;
+        for (int w = 0; w < MERGE_WAVES; ++w) total += wcount[w];
+        if (eq) {
+            const int pos = before + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < k) {
+                D[pos] = T;
+                I[pos] = i;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) filled += total;
+        __syncthreads();
+        if (filled >= k) break;
     }
 }
 
@@ -249,6 +444,8 @@ struct rag_csc {
     // top-k workspace
     double* cand_key = nullptr; int* cand_id = nullptr; int64_t cand_cap = 0;
     double* out_D = nullptr; long long* out_I = nullptr; int64_t out_cap = 0;
+    double* thr_ws = nullptr;   // [SPANS] span maxima + [1] threshold (threshold path of the top-k)
+    int* thr_cnt = nullptr;     // [2] appended scores, overflow flag
     long long* rk_rows = nullptr; unsigned long long* rk_out = nullptr;
     double* rk_skey = nullptr; long long* rk_srow = nullptr; int* rk_pos = nullptr; unsigned long long* rk_hist = nullptr;
     std::mutex mu;
@@ -273,11 +470,18 @@ int topk_scores(rag_csc* h, int k, double* D, int64_t* I, hipStream_t st) {
     const int KS = ks_for(k);
     long long nb = (h->n_rows + 4095) / 4096;  // >= 4096 rows per block
     nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
-    if (nb * k > h->cand_cap) {
+    // threshold path for large score vectors (see span_max_kernel); the list kernels stay enqueued
+    // behind it and return at once unless its buffer overflowed
+    const bool thr_path = h->n_rows >= 65536 && k <= SPANS / 4 && options().sparse_topk_lists == 0;
+    if (thr_path && h->thr_ws == nullptr) {
+        RAG_HIP(hipMalloc(&h->thr_ws, (size_t)(SPANS + 1) * sizeof(double)));
+        RAG_HIP(hipMalloc(&h->thr_cnt, 4 * sizeof(int)));
+    }
+    if (std::max<long long>(nb * k, thr_path ? 2 * THR_CAP : 0) > h->cand_cap) {
         if (h->cand_key) RAG_HIP(hipFree(h->cand_key));
         if (h->cand_id) RAG_HIP(hipFree(h->cand_id));
         h->cand_key = nullptr; h->cand_id = nullptr; h->cand_cap = 0;
-        const int64_t want = std::max<int64_t>(nb * k, 4096);
+        const int64_t want = std::max<int64_t>(nb * k, 2 * THR_CAP);
         RAG_HIP(hipMalloc(&h->cand_key, (size_t)want * sizeof(double)));
         RAG_HIP(hipMalloc(&h->cand_id, (size_t)want * sizeof(int)));
         h->cand_cap = want;
@@ -290,12 +494,34 @@ int topk_scores(rag_csc* h, int k, double* D, int64_t* I, hipStream_t st) {
         RAG_HIP(hipMalloc(&h->out_I, (size_t)RAG_MAX_K * sizeof(long long)));
         h->out_cap = RAG_MAX_K;
     }
+    const int* flag = nullptr;
+    if (thr_path) {
+        double* wmax = h->thr_ws;
+        double* thr = h->thr_ws + SPANS;
+        flag = h->thr_cnt + 1;
+        span_max_kernel<<<SPANS / 4, 256, 0, st>>>(h->score, (long long)h->n_rows, wmax);
+        kth_span_max_kernel<<<1, SPANS, 0, st>>>(wmax, k, thr, h->thr_cnt);
+        const long long cb = std::min<long long>((h->n_rows + 255) / 256, (long long)num_cus() * 8);
+        int* eq_id = h->cand_id + THR_CAP;
+        compact_gt_kernel<<<(unsigned)cb, 256, 0, st>>>(h->score, (long long)h->n_rows, thr, h->cand_key, h->cand_id,
+                                                        eq_id, h->thr_cnt);
+        if (KS == 1)
+            select_fill_kernel<1><<<1, MERGE_THREADS, 0, st>>>(h->score, (long long)h->n_rows, thr, h->cand_key,
+                                                               h->cand_id, eq_id, h->thr_cnt, k, h->out_D, h->out_I);
+        else if (KS == 2)
+            select_fill_kernel<2><<<1, MERGE_THREADS, 0, st>>>(h->score, (long long)h->n_rows, thr, h->cand_key,
+                                                               h->cand_id, eq_id, h->thr_cnt, k, h->out_D, h->out_I);
+        else
+            select_fill_kernel<4><<<1, MERGE_THREADS, 0, st>>>(h->score, (long long)h->n_rows, thr, h->cand_key,
+                                                               h->cand_id, eq_id, h->thr_cnt, k, h->out_D, h->out_I);
+        RAG_HIP(hipGetLastError());
+    }
 #define LAUNCH_TOPK(KSV)                                                                                   \
     do {                                                                                                   \
         dense_topk_kernel<KSV><<<(unsigned)nb, TK_THREADS, 0, st>>>(h->score, (long long)h->n_rows, k,     \
-                                                                    h->cand_key, h->cand_id);             \
+                                                                    h->cand_key, h->cand_id, flag);       \
         dense_topk_merge_kernel<KSV><<<1, MERGE_THREADS, 0, st>>>(h->cand_key, h->cand_id, (int)nb, k,     \
-                                                                  h->out_D, h->out_I);                     \
+                                                                  h->out_D, h->out_I, flag);               \
     } while (0)
     if (KS == 1) LAUNCH_TOPK(1);
     else if (KS == 2) LAUNCH_TOPK(2);
@@ -365,6 +591,8 @@ void rag_csc_free(rag_csc_t* h) {
     (void)hipFree(h->cand_id);
     (void)hipFree(h->out_D);
     (void)hipFree(h->out_I);
+    (void)hipFree(h->thr_ws);
+    (void)hipFree(h->thr_cnt);
     (void)hipFree(h->rk_rows);
     (void)hipFree(h->rk_out);
     (void)hipFree(h->rk_skey);

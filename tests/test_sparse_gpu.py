@@ -194,3 +194,52 @@ def test_csc_large_single_term_and_many_rows(engine):
     full_rank = np.empty(n, dtype=np.int64)
     full_rank[np.lexsort((np.arange(n), -exp))] = np.arange(n)
     assert h.ranks(q).tolist() == full_rank[q].tolist()
+
+
+def _topk_of_vector(h_cache, scores, k):
+    """Top-k of an arbitrary float64 vector through the TF-IDF entry point: one term present in
+    every row with val = the vector and query weight 1.0 gives score == val bit for bit."""
+    from rag_system_amd.bm25 import make_csc
+    n = len(scores)
+    h = make_csc(1, n, np.array([0, n], dtype=np.int64), np.arange(n, dtype=np.int32),
+                 np.ascontiguousarray(scores, dtype=np.float64))
+    s, D, I = h.tfidf_scores([0], [1.0], want_scores=True, k=k)
+    assert np.array_equal(_bits(s), _bits(scores))
+    return D, I
+
+
+def test_topk_threshold_path_matches_stable_sort(engine):
+    """Large score vectors take the threshold path of the top-k (span maxima -> k-th largest ->
+    append scores above it -> exact selection, ties completed by ascending row).  Checked
+    against the stable descending sort the reference takes (vector_storage.py:180), including
+    vectors that force the fallback to the list kernels, and against the list kernels alone."""
+    from rag_system_amd import _lib
+    lib = _lib.engine()
+    rng = np.random.default_rng(77)
+    n = 300_007
+    cases = {
+        "random": rng.standard_normal(n),
+        "few_positive": np.where(rng.random(n) < 0.0005, rng.random(n) * 7.0, 0.0),       # BM25 with rare terms
+        "ties_everywhere": rng.integers(0, 6, n).astype(np.float64),                       # 6 distinct values
+        "all_equal": np.full(n, 0.125),
+        "descending_by_row": np.linspace(5.0, -5.0, n),                                    # overflow -> list kernels
+        "ascending_by_row": np.linspace(-5.0, 5.0, n),
+        "one_span_holds_the_top": np.concatenate([rng.random(n - 200), 10.0 + rng.random(200)]),
+        "boundary_tie_far_away": np.concatenate([[3.0] * 50, rng.random(n - 52), [3.0, 3.0]]),
+    }
+    spread = rng.standard_normal(n)
+    spread[np.linspace(1000, n - 1000, 8).astype(np.int64)] = 4.0    # 8 equal scores far apart ...
+    cases["boundary_tie_spread"] = spread                             # ... around rank 10-20: k = 12 cuts the group
+    for name, sc in cases.items():
+        order = np.lexsort((np.arange(n), -sc))
+        for k in (1, 10, 12, 100, 256):
+            D, I = _topk_of_vector(None, sc, k)
+            assert I.tolist() == order[:k].tolist(), (name, k)
+            assert np.array_equal(_bits(D), _bits(sc[order[:k]])), (name, k)
+    try:
+        _lib.check(lib.rag_set_option(b"sparse_topk_lists", 1))
+        D, I = _topk_of_vector(None, cases["random"], 100)
+        order = np.lexsort((np.arange(n), -cases["random"]))
+        assert I.tolist() == order[:100].tolist()
+    finally:
+        lib.rag_set_option(b"sparse_topk_lists", 0)
