@@ -252,8 +252,8 @@ def main():
             kname = "flat_scan_kernel" if nq < (2 if bf else 3) else "flat_scan_kernel (pairs)"
         elif nq <= 8 or (nq <= 16 and n_local < (1 << 19)):
             kname = "flat_stream_kernel"
-        elif nq <= 64 and n_local >= (1 << 19):
-            kname = "flat_wide_kernel (sample + filter passes)"
+        elif nq <= 192 and n_local >= (1 << 19):
+            kname = "flat_wide_kernel (sample + filter passes%s)" % ("" if nq <= 64 else ", %d query chunks" % ((nq + 63) // 64))
         else:
             kname = "flat_mfma_kernel"
         roof.update({"kernel": kname, "avg_launch_ms": avg_scan_ms, "launches": n_launch,

@@ -661,6 +661,24 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     const int KS = ks_for(k > RAG_MAX_K ? RAG_MAX_K : k);
 
     int rc = RAG_OK;
+    // 65..192 queries on a large shard: two or three passes of the 16x16 register-fed kernel
+    // (flat_wide.hip, <= 64 queries per pass) beat the LDS tile kernel, whose 128-query block shapes
+    // are half empty there (10M x 384, benchmarks/run_mid_nq.sh: 65 / 96 / 128 / 192 queries
+    // 8.9 / 9.0 / 9.4 / 16.2 ms on the tile kernel against 3.65-4.5 ms per pass).
+    if (nq > 64 && nq <= 192 && k <= 128 && n >= opt.mfma_filter_min_rows && opt.mfma_filter_k <= 1 &&
+        (opt.wide_max_nq == 0 || opt.wide_max_nq >= 64) && opt.mfma_min_nq <= 64) {
+        WidePlan probe;
+        if (wide_plan(n, 64, dch, bf, 1, 1024, 32, &probe)) {
+            const int64_t nch = (nq + 63) / 64;
+            const int64_t per = ((nq + nch - 1) / nch + 15) & ~(int64_t)15;
+            for (int64_t c0 = 0; c0 < nq; c0 += per) {
+                const int64_t cn = std::min<int64_t>(per, nq - c0);
+                rc = search_device(h, cn, q_dev + c0 * h->d, k, D_dev + c0 * k, I_dev + c0 * k, id_base, st);
+                if (rc) return rc;
+            }
+            return RAG_OK;
+        }
+    }
     // fp32 rows whose length needs no padding: the kernels read the caller's queries directly
     const bool q_direct = !bf && ld == h->d && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0;
     const float* qf = q_dev;  // nq x ld fp32 queries as the kernels see them

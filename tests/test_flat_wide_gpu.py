@@ -63,7 +63,9 @@ def test_wide_kernel_matches_oracle(engine, metric, storage):
                 X[n - 1] = X[3]
             idx = faiss.IndexFlat(d, metric, storage=storage)
             idx.add(X)
-            for nq, k in [(17, 10), (32, 1), (33, 64), (48, 33), (49, 100), (64, 128), (64, 10), (20, 5)]:
+            # 65..192 queries: two or three passes of at most 64 queries each
+            for nq, k in [(17, 10), (32, 1), (33, 64), (48, 33), (49, 100), (64, 128), (64, 10), (20, 5),
+                          (65, 10), (100, 33), (129, 5), (192, 100)]:
                 Q = _rand_unit(rng, nq, d)
                 Q[0] = X[min(3, n - 1)]
                 _check(idx, X, Q, k, metric, storage)
@@ -147,7 +149,8 @@ def test_wide_kernel_default_on_a_large_shard(engine):
     idx._b.add_synthetic(n, seed, 0)
     Q = od.synth_queries(6, 64, d)
     Q[1] = od.synth_rows(seed, 1_234_567, 1, d)[0]
-    for nq, k in [(64, 10), (33, 100)]:
+    Q = np.concatenate([Q, od.synth_queries(7, 36, d)])
+    for nq, k in [(64, 10), (33, 100), (100, 10)]:
         D, I = idx.search(Q[:nq], k)
         _, Ir, D64 = od.flat_search_synth(seed, 0, n, d, Q[:nq], k)
 
