@@ -48,10 +48,12 @@ def _check(idx, X, Q, k, metric, storage):
 
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 @pytest.mark.parametrize("metric", [0, 1])
-@pytest.mark.parametrize("n,d", [(1, 384), (7, 64), (300, 384), (4099, 768), (3001, 37), (20_011, 384), (1000, 20),
-                                 (513, 8), (2000, 1000), (50_003, 72)])
+@pytest.mark.parametrize("n,d", [(1, 384), (7, 64), (16, 384), (17, 40), (31, 768), (300, 384), (4099, 768), (3001, 37),
+                                 (20_011, 384), (1000, 20), (513, 8), (2000, 1000), (50_003, 72), (200, 4096)])
 def test_list_mode_matches_oracle(engine, n, d, metric, storage):
-    """d = 37, 20, 8, 72, 1000: rows that end inside a 256-byte segment; n = 1, 7, 513: ragged tiles."""
+    """d = 37, 20, 8, 72, 1000: rows that end inside a 256-byte segment; n = 16, 17, 31, 513: a single
+    or a window-shifted last wave tile (n = 1, 7: below the kernel's 16 rows, served by the tile
+    kernel); d = 4096: the longest fp32 rows whose queries still fit the kernel's LDS budget."""
     from rag_system_amd import faiss_compat as faiss
     rng = np.random.default_rng(n * 11 + d + metric)
     X = _rand_unit(rng, n, d)
@@ -60,7 +62,7 @@ def test_list_mode_matches_oracle(engine, n, d, metric, storage):
         X[n - 1] = X[3]
     idx = faiss.IndexFlat(d, metric, storage=storage)
     idx.add(X)
-    for nq, k in [(3, 10), (4, 1), (5, 64), (8, 33), (9, 100), (12, 128), (16, 10), (16, 65), (2, 10)]:
+    for nq, k in [(3, 10), (4, 1), (5, 64), (8, 33), (9, 100), (12, 128), (16, 10), (16, 65), (2, 10), (1, 10), (1, 100), (2, 128)]:
         Q = _rand_unit(rng, nq, d)
         Q[0] = X[min(3, n - 1)]
         _check(idx, X, Q, k, metric, storage)
