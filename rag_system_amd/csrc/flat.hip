@@ -50,6 +50,7 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 constexpr int MERGE_THREADS = 1024;
 constexpr int MERGE_WAVES = MERGE_THREADS / 64;
+constexpr int SELECT_SORT_MAX = 2048;  // filter_select_kernel sorts up to this many candidates in LDS
 
 // ---------------------------------------------------------------- scan kernel
 
@@ -333,6 +334,47 @@ __global__ __launch_bounds__(MERGE_THREADS) void filter_select_kernel(
     if (!ok) return;
     const float* ck = cand_key + q * cap;
     const int* ci = cand_id + q * cap;
+    if (cnt <= (unsigned int)SELECT_SORT_MAX) {
+        // Up to 2048 candidates (the usual few hundred): bitonic sort in LDS of 64-bit composites
+        // (order-preserving key bits, then ~id, so that descending = key descending, id ascending)
+        // -- 45-66 compare-exchange steps, ~8 us, against 15-45 us of sorted inserts.
+        __shared__ unsigned long long sv[SELECT_SORT_MAX];
+        const int N = cnt <= 1024u ? 1024 : SELECT_SORT_MAX;
+        for (int i = threadIdx.x; i < N; i += MERGE_THREADS) {
+            unsigned long long c = 0ULL;
+            if (i < (int)cnt) {
+                unsigned int u = __float_as_uint(ck[i]);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                c = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ci[i]);
+            }
+            sv[i] = c;
+        }
+        __syncthreads();
+        for (int size = 2; size <= N; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int p = threadIdx.x; p < N / 2; p += MERGE_THREADS) {
+                    const int i = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
+                    const int j = i + stride;
+                    const bool desc = (i & size) == 0;
+                    const unsigned long long a = sv[i], b = sv[j];
+                    if (desc ? a < b : a > b) {
+                        sv[i] = b;
+                        sv[j] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int p = threadIdx.x; p < k; p += MERGE_THREADS) {
+            const unsigned long long c = sv[p];
+            unsigned int u = (unsigned int)(c >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+            const float key = __uint_as_float(u);
+            D[q * k + p] = METRIC == RAG_METRIC_IP ? key : -key;
+            I[q * k + p] = id_base + (long long)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFULL));
+        }
+        return;
+    }
     WaveTopK<float, int, KS> tk;
     block_merge<float, int, KS, MERGE_WAVES>(
         [&](long long c, float& key, int& id) {
