@@ -397,6 +397,37 @@ __global__ __launch_bounds__(MERGE_THREADS) void filter_select_kernel(
     }
 }
 
+// Threshold of the filter flows whose sample pass leaves ONE best score per wave or block and
+// query (vals[q*stride + i], i < count <= 4096; -FLT_MAX = nothing seen): thr[q] = the j-th largest,
+// by a bitonic sort in LDS.  Fewer than j real values -> -FLT_MAX (every row passes, the query
+// overflows its buffer and is redone in list mode).
+__global__ __launch_bounds__(MERGE_THREADS) void kth_largest_kernel(const float* __restrict__ vals, int stride,
+                                                                    int count, int j, float* __restrict__ thr) {
+    __shared__ float v[4096];
+    const float* src = vals + (long long)blockIdx.x * stride;
+    count = count < 4096 ? count : 4096;  // more values than fit: the rest could only raise the threshold
+    int N = 64;
+    while (N < count) N <<= 1;
+    for (int i = threadIdx.x; i < N; i += MERGE_THREADS) v[i] = i < count ? src[i] : -FLT_MAX;
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            for (int p = threadIdx.x; p < N / 2; p += MERGE_THREADS) {
+                const int i = ((p & ~(st - 1)) << 1) | (p & (st - 1));
+                const int jx = i + st;
+                const bool desc = (i & size) == 0;
+                const float a = v[i], b = v[jx];
+                if (desc ? a < b : a > b) {
+                    v[i] = b;
+                    v[jx] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) thr[blockIdx.x] = j <= N ? v[j - 1] : -FLT_MAX;
+}
+
 // floor of pass p+1 = last entry of pass p (position `pos` of each query's output row).
 __global__ void make_floor_kernel(const float* __restrict__ D, const long long* __restrict__ I, long long nq,
                                   int stride, int pos, int metric, long long id_base, float* __restrict__ fk,
@@ -790,10 +821,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         // over all rows, in list mode or as the filter pass; sample pass and redo stay with the tile kernel
         StreamPlan sp, sps;
         const bool stream = !wide && stream_plan(n, nq, k, dch, bf, filter, cap, 1, &sp) &&
-                            (!filter || stream_plan(n, nq, j, dch, bf, false, 0, FILTER_STEP, &sps));
+                            (!filter || stream_plan(n, nq, 1, dch, bf, false, 0, FILTER_STEP, &sps));
         int64_t need = nq * plan.nlists * k;
         if (stream && !filter) need = std::max<int64_t>(need, nq * (int64_t)sp.nlists * k);
-        if (stream && filter) need = std::max<int64_t>(need, nq * (int64_t)sps.nlists * j);
+        if (stream && filter) need = std::max<int64_t>(need, nq * (int64_t)sps.nlists);
         if (wide && filter) need = std::max<int64_t>(need, nq * (int64_t)wp.wpad);
         if (filter) need = std::max<int64_t>(need, std::max<int64_t>(nq * ps.nlists * j, nq * (int64_t)cap));
         rc = grow(h->ws_key, h->ws_key_cap, need);
@@ -871,26 +902,31 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             RAG_HIP(hipGetLastError());
             return RAG_OK;
         }
-        // 1. sample pass (list mode over every FILTER_STEP-th row tile) -> j best per query -> threshold
+        // 1. sample pass over every FILTER_STEP-th row tile -> threshold per query.  The register-fed
+        // kernels leave one best score per wave (wide) or block (stream, list mode with k = 1) and the
+        // j-th largest of those is the threshold: it equals the j-th best sampled row unless two of
+        // the best j fell to one wave / block, which only lowers it.  The tile kernel keeps j per list.
         ps.tile_step = FILTER_STEP;
-        if (wide)
+        if (wide) {
             rc = wide_sample(wp, h->x, (long long)n, dch, Qw, (int)nq, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
                              st);
-        else if (stream)
-            rc = stream_launch(sps, h->x, (long long)n, dch, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm,
+            if (rc) return rc;
+            kth_largest_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, wp.wpad, wp.blocks * wp.wpb, j,
+                                                                       h->ws_thr);
+        } else if (stream) {
+            rc = stream_launch(sps, h->x, (long long)n, dch, Qw, (int)nq, 1, h->metric, h->ws_key, h->ws_id, h->xnorm,
                                h->ws_qn, st);
-        else
+            if (rc) return rc;
+            kth_largest_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, sps.nlists, sps.nlists, j, h->ws_thr);
+        } else {
             rc = mfma_launch(ps, Xw, (long long)n, ldw, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm,
                              h->ws_qn, h->zero16, st);
-        if (rc) return rc;
-        pick_merge(1, h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id,
-                                                                        wide     ? wp.wpad / j
-                                                                        : stream ? sps.nlists
-                                                                                 : ps.nlists,
-                                                                        j, h->ws_sD,
-                                                                        h->ws_sI, 0LL, j, 0, nullptr);
-        make_floor_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, st>>>(h->ws_sD, h->ws_sI, nq, j, j - 1, h->metric, 0LL,
-                                                                       h->ws_thr, h->ws_fi);
+            if (rc) return rc;
+            pick_merge(1, h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, ps.nlists, j, h->ws_sD,
+                                                                            h->ws_sI, 0LL, j, 0, nullptr);
+            make_floor_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, st>>>(h->ws_sD, h->ws_sI, nq, j, j - 1, h->metric,
+                                                                           0LL, h->ws_thr, h->ws_fi);
+        }
         RAG_HIP(hipGetLastError());
         // 2. filter pass over all rows
         unsigned int* counts = reinterpret_cast<unsigned int*>(h->ws_cnt);
