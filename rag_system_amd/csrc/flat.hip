@@ -232,6 +232,93 @@ __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
     if (only_if != nullptr && only_if[q] == 0) return;  // redo pass: only the queries that failed
     const float* ck = cand_key + q * (long long)nlists * k;
     const int* ci = cand_id + q * (long long)nlists * k;
+    // Fast path (up to 4096 sorted lists): the k-th largest list HEAD T bounds the result from below
+    // -- k heads are >= T, so every entry of the global top-k is >= T -- and the entries >= T are a
+    // prefix of the few lists whose head is >= T: typically k..3k candidates out of nlists*k.  Both
+    // steps are LDS bitonic sorts (heads: 55-78 compare-exchange steps; candidates: a few), ~9 us for
+    // 1024 lists whatever k is, against 24 us (k = 10) to 195 us (k = 100) of list merging below,
+    // which remains the path for more lists or more than 2048 candidates (long tie runs).
+    if (nlists <= 4096) {
+        __shared__ unsigned long long sv[SELECT_SORT_MAX];
+        __shared__ int n_cand;
+        float* hv = reinterpret_cast<float*>(sv);  // 4096 floats = the same 16 KiB
+        int N = 64;
+        while (N < nlists) N <<= 1;
+        for (int i = threadIdx.x; i < N; i += MERGE_THREADS) hv[i] = i < nlists ? ck[(long long)i * k] : -FLT_MAX;
+        if (threadIdx.x == 0) n_cand = 0;
+        __syncthreads();
+        for (int size = 2; size <= N; size <<= 1) {
+            for (int st = size >> 1; st > 0; st >>= 1) {
+                for (int p = threadIdx.x; p < N / 2; p += MERGE_THREADS) {
+                    const int i = ((p & ~(st - 1)) << 1) | (p & (st - 1));
+                    const int j = i + st;
+                    const bool desc = (i & size) == 0;
+                    const float a = hv[i], b = hv[j];
+                    if (desc ? a < b : a > b) {
+                        hv[i] = b;
+                        hv[j] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const float T = k <= N ? hv[k - 1] : -FLT_MAX;
+        __syncthreads();  // everyone has T before the buffer is reused
+        for (int l = threadIdx.x; l < nlists; l += MERGE_THREADS) {
+            const float* lk = ck + (long long)l * k;
+            const int* li = ci + (long long)l * k;
+            for (int p = 0; p < k; ++p) {
+                const float key = lk[p];
+                const int id = li[p];
+                if (!(key >= T) || id == IdPad<int>::v()) break;  // sorted: the rest is below T (or padding)
+                const int slot = atomicAdd(&n_cand, 1);
+                if (slot < SELECT_SORT_MAX) {
+                    unsigned int u = __float_as_uint(key);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    sv[slot] = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)id);
+                }
+            }
+        }
+        __syncthreads();
+        const int cnt = n_cand;
+        if (cnt <= SELECT_SORT_MAX) {  // uniform
+            int M = 64;
+            while (M < cnt) M <<= 1;
+            for (int i = cnt + threadIdx.x; i < M; i += MERGE_THREADS) sv[i] = 0ULL;
+            __syncthreads();
+            for (int size = 2; size <= M; size <<= 1) {
+                for (int st = size >> 1; st > 0; st >>= 1) {
+                    for (int p = threadIdx.x; p < M / 2; p += MERGE_THREADS) {
+                        const int i = ((p & ~(st - 1)) << 1) | (p & (st - 1));
+                        const int j = i + st;
+                        const bool desc = (i & size) == 0;
+                        const unsigned long long a = sv[i], b = sv[j];
+                        if (desc ? a < b : a > b) {
+                            sv[i] = b;
+                            sv[j] = a;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int p = threadIdx.x; p < k; p += MERGE_THREADS) {
+                const long long o = q * out_stride + out_off + p;
+                if (p < cnt) {
+                    const unsigned long long c = sv[p];
+                    unsigned int u = (unsigned int)(c >> 32);
+                    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+                    const float key = __uint_as_float(u);
+                    D[o] = METRIC == RAG_METRIC_IP ? key : -key;
+                    I[o] = id_base + (long long)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFULL));
+                } else {
+                    D[o] = METRIC == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX;
+                    I[o] = -1LL;
+                }
+            }
+            return;
+        }
+        __syncthreads();
+    }
     WaveTopK<float, int, KS> tk;
     if (KS == 1 && k <= 32) {
         // short lists: several lists share a 64-candidate chunk (flat walk, sorted inserts)
@@ -798,9 +885,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         MfmaPlan ps, pf;
         // measured crossover (benchmarks/run_filter_k.sh): nq = 64: filter mode wins from k = 16;
         // nq = 1024 (one list per query and block): from k = 32
-        // stream kernel (nq <= 16, lists in registers; benchmarks/run_stream_k.sh): up to 8 queries
-        // list mode holds up to k = 64 (nq 8, k 64: 2.60 ms against 2.68), 9..16 queries up to k ~ 16
-        // (nq 16, k 32: 3.24 ms against 2.85)
+        // stream kernel (nq <= 16, lists in registers; benchmarks/run_stream_k.sh): 1..3 queries
+        // list mode for every k <= 128 (the merge of the block lists costs ~10 us whatever k is:
+        // nq 1, k 100: 2.23 ms against 2.28 in filter mode), 4..8 queries up to k = 64 (nq 8, k 100:
+        // 3.0 ms against 2.48), 9..16 queries up to k ~ 16 (nq 16, k 32: 3.24 ms against 2.85)
         StreamPlan probe;
         const bool stream_ok = stream_plan(n, nq, 1, dch, bf, false, 0, 1, &probe);
         // 17..64 queries on a large shard: the 16x16 register-fed kernel (flat_wide.hip), which only
@@ -812,7 +900,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                           wide_plan(n, nq, dch, bf, j, cap, FILTER_STEP, &wp);
         const int64_t filter_k = opt.mfma_filter_k > 0 ? opt.mfma_filter_k
                                  : wide                ? 1
-                                 : stream_ok           ? (nq > 8 ? 24 : 65)
+                                 : stream_ok           ? (nq > 8 ? 24 : (nq >= 4 ? 65 : 129))
                                                        : (nq <= 128 ? 16 : 33);
         const bool filter = k >= filter_k && n >= opt.mfma_filter_min_rows &&
                             mfma_plan(std::max<long long>(1, n / FILTER_STEP), nq, j, bf, &ps) &&
