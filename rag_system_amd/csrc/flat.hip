@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -647,6 +648,7 @@ struct rag_flat {
     int64_t norm_valid = 0;
     float* ws_hq = nullptr;  int64_t ws_hq_cap = 0;    // host-variant device copies
     float* ws_D = nullptr; long long* ws_I = nullptr; int64_t ws_out_cap = 0;
+    char* pin = nullptr; size_t pin_cap = 0;            // pinned staging of the host variant (small batches)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
@@ -1184,6 +1186,7 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->xnorm);
         (void)hipFree(h->ws_D);
         (void)hipFree(h->ws_I);
+        if (h->pin) (void)hipHostFree(h->pin);
         for (auto& p : h->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto& p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     }
@@ -1318,12 +1321,36 @@ int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, 
         RAG_HIP(hipMalloc(&h->ws_I, (size_t)want * sizeof(long long)));
         h->ws_out_cap = want;
     }
-    RAG_HIP(hipMemcpyAsync(h->ws_hq, q, (size_t)nq * h->d * sizeof(float), hipMemcpyHostToDevice, st));
+    // Small batches (the reference's one query per call): queries and results go through a pinned
+    // staging buffer, so the three copies are truly asynchronous DMA transfers behind one
+    // synchronisation instead of three staged pageable copies.
+    const size_t qb = (size_t)nq * h->d * sizeof(float), db = (size_t)nq * k * sizeof(float),
+                 ib = (size_t)nq * k * sizeof(long long);
+    const size_t qoff = 0, ioff = (qb + 15) & ~(size_t)15, doff = ioff + ((ib + 15) & ~(size_t)15);
+    const size_t need = doff + db;
+    const bool staged = need <= ((size_t)4 << 20);
+    if (staged && need > h->pin_cap) {
+        if (h->pin) RAG_HIP(hipHostFree(h->pin));
+        h->pin = nullptr; h->pin_cap = 0;
+        const size_t want = std::max<size_t>(need, (size_t)64 << 10);
+        RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), want, hipHostMallocDefault));
+        h->pin_cap = want;
+    }
+    if (staged) {
+        std::memcpy(h->pin + qoff, q, qb);
+        RAG_HIP(hipMemcpyAsync(h->ws_hq, h->pin + qoff, qb, hipMemcpyHostToDevice, st));
+    } else {
+        RAG_HIP(hipMemcpyAsync(h->ws_hq, q, qb, hipMemcpyHostToDevice, st));
+    }
     rc = search_device(h, nq, h->ws_hq, k, h->ws_D, h->ws_I, 0, st);
     if (rc) return rc;
-    RAG_HIP(hipMemcpyAsync(D, h->ws_D, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
-    RAG_HIP(hipMemcpyAsync(I, h->ws_I, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(staged ? (void*)(h->pin + doff) : (void*)D, h->ws_D, db, hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(staged ? (void*)(h->pin + ioff) : (void*)I, h->ws_I, ib, hipMemcpyDeviceToHost, st));
     RAG_HIP(hipStreamSynchronize(st));
+    if (staged) {
+        std::memcpy(D, h->pin + doff, db);
+        std::memcpy(I, h->pin + ioff, ib);
+    }
     return RAG_OK;
 }
 

@@ -29,7 +29,7 @@ int stream_launch(const StreamPlan& p, const void* X, long long n, int dch, cons
                   float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st,
                   const int* run_flag = nullptr, const float* thr_q = nullptr, unsigned int* counts = nullptr);
 
-// ---- flat_wide.hip: 17..64 queries, 16x16 MFMA fed from registers, sample + filter passes only
+// ---- flat_wide.hip: 9..64 queries per pass, 16x16 MFMA fed from registers, sample + filter passes only
 struct WidePlan {
     int NT;           // query tiles of 16
     bool bf16;

@@ -1,4 +1,4 @@
-// flat_wide.hip -- exact top-k of a medium query batch (17..64 queries) over a row-major matrix:
+// flat_wide.hip -- exact top-k of a medium query batch (9..64 queries per pass) over a row-major matrix:
 // rows streamed from HBM straight into 16x16 MFMA operands, no LDS staging of the matrix and no
 // barrier after the queries are in LDS -- every wave runs its own load -> multiply pipeline.
 //

@@ -1,5 +1,5 @@
 """GPU parity tests of the register-fed small-batch kernel (csrc/flat_stream.hip): batches of
-3..16 queries (2..16 for bfloat16 rows), k <= 128, list mode and filter mode.
+1..16 queries, k <= 128, list mode and filter mode.
 
 Checked against the float64 oracle (oracle/dense.py, restating vector_storage.py:159-195 and the
 IndexFlat.search call at :257-271) to the fp32 bar of BASELINE.json (1e-5 relative, ids identical
