@@ -29,6 +29,7 @@ struct Options {
     int64_t mfma_bpc = 0;      // force MFMA blocks per CU used to size the row split (0 = auto)
     int64_t mfma_filter_k = 0;             // k >= this -> MFMA filter mode (0 = auto: 16 up to 128 queries, else 33)
     int64_t mfma_filter_min_rows = 1 << 19;  // ... on shards of at least this many rows
+    int64_t mfma_filter_step = 0;            // sample every N-th row tile (0 = auto: 32, 64 for 256+ queries on 4M+ rows)
     int64_t stream_max_nq = 0;  // batches up to this size take the register-fed stream kernel (0 = auto: 16; -1 = never)
     int64_t stream_rg = 0;      // row groups of 4 per wave tile, 2 or 4 (0 = auto)
     int64_t stream_bpc = 0;     // stream kernel blocks per CU (0 = auto)

@@ -879,7 +879,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         // E[count] = j*step and sd ~ step*sqrt(j), j = (2 + sqrt(4 + k/step))^2 puts k four
         // deviations below the mean; queries that still end outside [k, cap] (ties, skewed row
         // order) are redone by the list-mode kernel, which otherwise returns at once.
-        constexpr int FILTER_STEP = 32;
+        // sample stride: 1/32 of the row tiles; 1/64 for batches of 256+ queries on 4M+ rows, where the
+        // list-mode sample pass of the tile kernel is a tenth of the whole search ("mfma_filter_step")
+        const int FILTER_STEP = opt.mfma_filter_step > 0 ? (int)std::min<int64_t>(opt.mfma_filter_step, 1024)
+                                : (nq >= 256 && n >= (4LL << 20) ? 64 : 32);
         const double root = 2.0 + std::sqrt(4.0 + (double)k / FILTER_STEP);
         const int j = std::min(64, (int)std::ceil(root * root));
         int cap = 1024;

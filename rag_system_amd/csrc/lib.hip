@@ -92,6 +92,7 @@ int rag_set_option(const char* name, int64_t value) {
     else if (!std::strcmp(name, "mfma_stages")) o.mfma_stages = value;
     else if (!std::strcmp(name, "mfma_filter_k")) o.mfma_filter_k = value;
     else if (!std::strcmp(name, "mfma_filter_min_rows")) o.mfma_filter_min_rows = value;
+    else if (!std::strcmp(name, "mfma_filter_step")) o.mfma_filter_step = value;
     else if (!std::strcmp(name, "stream_max_nq")) o.stream_max_nq = value;
     else if (!std::strcmp(name, "stream_rg")) o.stream_rg = value;
     else if (!std::strcmp(name, "stream_bpc")) o.stream_bpc = value;
