@@ -191,5 +191,14 @@ def test_config3_shape_10M_x_768_top100_batch1024(engine):
             return rows.astype(np.float64) @ Qr[qs[qi]].astype(np.float64)
         return f
     od.check_topk(D[sel], I[sel], D64, Ir, RTOL, ATOL, scorer_for(sel))
-    D1, I1 = idx.search(Q[sel], k)                          # nq = 3 -> scan kernel
+    D1, I1 = idx.search(Q[sel], k)                          # nq = 3 -> stream kernel, list mode
     od.check_topk(D1, I1, D64, Ir, RTOL, ATOL, scorer_for(sel))
+    # the same three queries in batches served by the other kernels: 1 (stream), 8 (stream, filter
+    # mode), 16 and 64 (16x16 register-fed kernel), 100 (tile kernel)
+    for nqb in (1, 8, 16, 64, 100):
+        pos = [0] if nqb == 1 else [0, nqb // 2, nqb - 1]
+        B = Q[100:100 + nqb].copy()
+        for j, p in enumerate(pos):
+            B[p] = Q[sel[j]]
+        Db, Ib = idx.search(B, k)
+        od.check_topk(Db[pos], Ib[pos], D64[:len(pos)], Ir[:len(pos)], RTOL, ATOL, scorer_for(sel[:len(pos)]))

@@ -301,6 +301,32 @@ def test_full_size_10M_x_384_against_streaming_oracle(engine):
         return rows.astype(np.float64) @ Q[qi].astype(np.float64)
     od.check_topk(D, I, Dm.astype(np.float64), Im, RTOL, ATOL, scorer)
     assert I[2, 0] == 0 and I[2, 1] == n, "duplicate of row 0 must follow it (lower id first)"
+    # the same three queries inside batches of every size class -- stream kernel (1, 8), 16x16
+    # register-fed kernel (16, 64), its chunked passes (100), LDS tile kernel (300) -- at full size
+    filler = od.synth_queries(999, 300, d)
+    for nq in (1, 8, 16, 64, 100, 300):
+        B = filler[:nq].copy()
+        pos = [0] if nq == 1 else [0, nq // 2, nq - 1]
+        for j, p in enumerate(pos):
+            B[p] = Q[j]
+        Db, Ib = idx.search(B, k)
+        sel = np.asarray(pos)
+        od.check_topk(Db[sel], Ib[sel], Dm[:len(pos)].astype(np.float64), Im[:len(pos)], RTOL, ATOL, scorer)
+        assert (Ib >= 0).all() and (Ib < n + 2).all() and np.all(Db[:, :-1] >= Db[:, 1:])
+    # k = 100: list mode (3 queries), filter mode of the stream kernel (6) and of the 16x16 kernel (20)
+    k2 = 100
+    _, Ir2, D642 = od.flat_search_synth(seed, 0, n, d, Q, k2)
+    _, Ie2, De642 = od.flat_search(dup, Q, k2)
+    Ie2 = np.where(Ie2 >= 0, Ie2 + n, -1)
+    Dm2, Im2 = od.topk_merge(0, np.stack([D642.astype(np.float32), De642.astype(np.float32)]), np.stack([Ir2, Ie2]))
+    for nq in (3, 6, 20):
+        B = filler[:nq].copy()
+        pos = [0, nq // 2, nq - 1]
+        for j, p in enumerate(pos):
+            B[p] = Q[j]
+        Db, Ib = idx.search(B, k2)
+        sel = np.asarray(pos)
+        od.check_topk(Db[sel], Ib[sel], Dm2.astype(np.float64), Im2, RTOL, ATOL, scorer)
 
 
 @pytest.mark.parametrize("metric", [0, 1])
