@@ -803,6 +803,34 @@ merge_fn_t pick_merge(int KS, int metric) {
 
 int ks_for(int k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
 
+// L2 through the matrix-core kernels is ||x||^2 + ||q||^2 - 2<x,q>: row norms are computed once per
+// added row (kept next to the arena), query norms per call.
+int prepare_l2_norms(rag_flat* h, const float* qf, int64_t nq, hipStream_t st) {
+    if (h->metric != RAG_METRIC_L2) return RAG_OK;
+    const int64_t n = h->ndev;
+    const int ld = h->ld;
+    const bool bf = h->dtype == RAG_DTYPE_BF16;
+    int rc = RAG_OK;
+    if (h->xnorm_cap < h->cap) {  // follow the arena
+        float* nn = nullptr;
+        RAG_HIP(hipMalloc(&nn, (size_t)h->cap * sizeof(float)));
+        if (h->norm_valid > 0)
+            RAG_HIP(hipMemcpyAsync(nn, h->xnorm, (size_t)h->norm_valid * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RAG_HIP(hipStreamSynchronize(st));
+        if (h->xnorm) RAG_HIP(hipFree(h->xnorm));
+        h->xnorm = nn;
+        h->xnorm_cap = h->cap;
+    }
+    if (h->norm_valid < n) {
+        rc = mfma_row_norms(h->x, ld, bf, h->norm_valid, n - h->norm_valid, h->xnorm, st);
+        if (rc) return rc;
+        h->norm_valid = n;
+    }
+    rc = grow(h->ws_qn, h->ws_qn_cap, nq);
+    if (rc) return rc;
+    return mfma_row_norms(qf, ld, false, 0, nq, h->ws_qn, st);
+}
+
 // The whole device-side search: q_dev (nq x d) -> D_dev/I_dev (nq x k) on `st`.
 int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_dev, long long* I_dev,
                   int64_t id_base, hipStream_t st) {
@@ -924,27 +952,8 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         if (rc) return rc;
         rc = grow(h->ws_id, h->ws_id_cap, need);
         if (rc) return rc;
-        if (h->metric == RAG_METRIC_L2) {
-            if (h->xnorm_cap < h->cap) {  // follow the arena
-                float* nn = nullptr;
-                RAG_HIP(hipMalloc(&nn, (size_t)h->cap * sizeof(float)));
-                if (h->norm_valid > 0)
-                    RAG_HIP(hipMemcpyAsync(nn, h->xnorm, (size_t)h->norm_valid * sizeof(float), hipMemcpyDeviceToDevice, st));
-                RAG_HIP(hipStreamSynchronize(st));
-                if (h->xnorm) RAG_HIP(hipFree(h->xnorm));
-                h->xnorm = nn;
-                h->xnorm_cap = h->cap;
-            }
-            if (h->norm_valid < n) {
-                rc = mfma_row_norms(h->x, ld, bf, h->norm_valid, n - h->norm_valid, h->xnorm, st);
-                if (rc) return rc;
-                h->norm_valid = n;
-            }
-            rc = grow(h->ws_qn, h->ws_qn_cap, nq);
-            if (rc) return rc;
-            rc = mfma_row_norms(qf, ld, false, 0, nq, h->ws_qn, st);
-            if (rc) return rc;
-        }
+        rc = prepare_l2_norms(h, qf, nq, st);
+        if (rc) return rc;
         if (filter) {
             rc = grow(h->ws_sD, h->ws_sD_cap, nq * j);
             if (rc) return rc;
@@ -1063,6 +1072,50 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                                                    k, 0, failq);
         RAG_HIP(hipGetLastError());
         return RAG_OK;
+    }
+
+    // 128 < k <= 256 (document mode asks for 9 * top_k): the stream kernel with 256-entry lists, four
+    // queries per pass (10M x 384: 2.4 ms per pass against 2.4-2.6 ms per PAIR on the scan kernel)
+    if (k > 128 && k <= RAG_MAX_K && opt.mfma_min_nq <= 0 && nq <= INT_MAX) {
+        StreamPlan sp4;
+        if (stream_plan(n, std::min<int64_t>(nq, 4), k, dch, bf, false, 0, 1, &sp4)) {
+            rc = prepare_l2_norms(h, qf, nq, st);
+            if (rc) return rc;
+            const char* Qb = bf ? reinterpret_cast<const char*>(h->ws_qb) : reinterpret_cast<const char*>(qf);
+            const size_t qrow = (size_t)ld * h->esz;
+            merge_fn_t mf4 = pick_merge(4, h->metric);
+            for (int64_t q0 = 0; q0 < nq; q0 += 4) {
+                const int cn = (int)std::min<int64_t>(4, nq - q0);
+                if (!stream_plan(n, cn, k, dch, bf, false, 0, 1, &sp4)) return fail(RAG_ERR_HIP, "stream plan changed");
+                rc = grow(h->ws_key, h->ws_key_cap, (int64_t)cn * sp4.nlists * k);
+                if (rc) return rc;
+                rc = grow(h->ws_id, h->ws_id_cap, (int64_t)cn * sp4.nlists * k);
+                if (rc) return rc;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->prof) {
+                    if (!h->ev_free.empty()) {
+                        e0 = h->ev_free.back().first;
+                        e1 = h->ev_free.back().second;
+                        h->ev_free.pop_back();
+                    } else {
+                        RAG_HIP(hipEventCreate(&e0));
+                        RAG_HIP(hipEventCreate(&e1));
+                    }
+                    RAG_HIP(hipEventRecord(e0, st));
+                }
+                rc = stream_launch(sp4, h->x, (long long)n, dch, Qb + (size_t)q0 * qrow, cn, k, h->metric, h->ws_key,
+                                   h->ws_id, h->xnorm, h->ws_qn ? h->ws_qn + q0 : nullptr, st);
+                if (rc) return rc;
+                if (h->prof) {
+                    RAG_HIP(hipEventRecord(e1, st));
+                    h->ev_used.emplace_back(e0, e1);
+                }
+                mf4<<<(unsigned)cn, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, sp4.nlists, k, D_dev + q0 * k,
+                                                            I_dev + q0 * k, (long long)id_base, k, 0, nullptr);
+                RAG_HIP(hipGetLastError());
+            }
+            return RAG_OK;
+        }
     }
 
     // waves per CU (benchmarks/run_scan_threads_ab.sh): fp32 rows stream fastest with 12 (10M x 384:

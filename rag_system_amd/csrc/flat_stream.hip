@@ -374,6 +374,9 @@ int launch(const StreamPlan& p, const Args& a) {
 template <int G, int RG, bool BF>
 int launch_mode(const StreamPlan& p, const Args& a) {
     if (p.filt) return launch<G, RG, 1, BF, true>(p, a);
+    if constexpr (G == 1 && RG == 4) {  // 128 < k <= 256: four 256-entry lists per wave, one query group only
+        if (p.KS == 4) return launch<G, RG, 4, BF, false>(p, a);
+    }
     return p.KS == 1 ? launch<G, RG, 1, BF, false>(p, a) : launch<G, RG, 2, BF, false>(p, a);
 }
 
@@ -401,16 +404,17 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     const Options& opt = options();
     const long long max_nq = opt.stream_max_nq > 0 ? std::min<long long>(opt.stream_max_nq, 16) : 16;
     if (opt.stream_max_nq < 0 || nq < 1 || nq > max_nq || n < 1) return false;
-    if (!filt && (k < 1 || k > 128)) return false;
+    if (!filt && (k < 1 || k > 256 || (k > 128 && nq > 4))) return false;
     if (n < 16) return false;  // a wave tile is up to 16 rows; tiny shards go to the tile kernel
     p->G = nq <= 4 ? 1 : (nq <= 8 ? 2 : 4);
-    p->KS = k <= 64 ? 1 : 2;
+    p->KS = k <= 64 ? 1 : (k <= 128 ? 2 : 4);
     p->bf16 = bf16;
     p->filt = filt;
     p->cap = cap;
     p->tile_step = tile_step < 1 ? 1 : tile_step;
     p->RG = opt.stream_rg == 2 || opt.stream_rg == 4 ? (int)opt.stream_rg : (p->G == 4 ? 2 : 4);
     if (p->G == 4) p->RG = 2;
+    if (p->KS == 4) p->RG = 4;  // the only shape built with 256-entry lists
     const int dchp = ((dch + 16 * NB - 1) / (16 * NB)) * (16 * NB);
     const size_t qbytes = (size_t)p->G * dchp * 64;
     const size_t mbytes = filt ? 0 : (size_t)(ST_WAVES - 1) * 4 * p->G * p->KS * 64 * 8;
