@@ -129,9 +129,11 @@ int rag_flat_profiling(rag_flat_t* h, int enable);
 int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double* bytes_per_launch);
 /* Tuning knobs for A/B runs in one process: "scan_blocks", "scan_nt",
  * "scan_rows", "mfma_min_nq", "mfma_shape" (1..9), "mfma_bpc", "mfma_stages" (2..3),
- * "mfma_filter_k", "mfma_filter_min_rows" (when the batch kernels use thresholds + append buffers),
+ * "mfma_filter_k", "mfma_filter_min_rows", "mfma_filter_step" (when the batch kernels use thresholds +
+ * append buffers, and how densely the rows are sampled for the thresholds),
  * "stream_max_nq" (-1: never), "stream_rg", "stream_bpc" (register-fed kernel for up to 16 queries),
- * "wide_max_nq" (-1: never), "wide_min_nq", "wide_wpb" (register-fed kernel for 9..64 queries).
+ * "wide_max_nq" (-1: never), "wide_min_nq", "wide_wpb" (register-fed kernel for 9..64 queries),
+ * "sparse_topk_lists" (1: BM25 / TF-IDF top-k by the list kernels only, no threshold path).
  * Unknown name -> RAG_ERR_INVALID_ARG.  The selected ids never depend on them; scores are
  * bit-identical within one kernel and equal up to the fp32 summation order across kernels
  * (tests/test_flat_gpu.py, test_flat_stream_gpu.py, test_flat_wide_gpu.py). */
