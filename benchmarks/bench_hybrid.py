@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
     ap.add_argument("--cpu-queries", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--profile-loop", action="store_true", help="cProfile the timed query loop (stderr)")
     args = ap.parse_args()
     n, V, d, top_k = args.docs, args.vocab, args.dim, args.top_k
 
@@ -162,8 +163,20 @@ def main():
     for qi in range(min(3, args.queries)):
         one_query(qi, False)
     log("timing %d queries" % args.queries)
+    prof = None
+    if args.profile_loop:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     for qi in range(args.queries):
         results.append(one_query(qi, True))
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(30)
+        print(buf.getvalue(), file=sys.stderr)
     nq = float(args.queries)
     per_stage_ms = {s: tsum[s] / nq * 1e3 for s in stages}
 

@@ -8,7 +8,10 @@
 #include "common.h"
 
 #include <cfloat>
+#include <algorithm>
 #include <climits>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -209,15 +212,37 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
     if (tid == 0) *out_n = n_sel;
 }
 
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) {
-        RAG_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+inline size_t al8(size_t b) { return (b + 7) & ~(size_t)7; }
+
+// Process-wide workspace of the candidate-set calls (they are serialised by its mutex).
+struct CandWs {
+    std::mutex mu;
+    char* dev = nullptr;
+    size_t dev_cap = 0;
+    char* pin = nullptr;
+    size_t pin_cap = 0;
+    int reserve(size_t dev_bytes, size_t pin_bytes) {
+        if (dev_bytes > dev_cap) {
+            if (dev) RAG_HIP(hipFree(dev));
+            dev = nullptr; dev_cap = 0;
+            const size_t want = std::max<size_t>(dev_bytes * 2, (size_t)1 << 20);
+            RAG_HIP(hipMalloc(reinterpret_cast<void**>(&dev), want));
+            dev_cap = want;
+        }
+        if (pin_bytes > pin_cap) {
+            if (pin) RAG_HIP(hipHostFree(pin));
+            pin = nullptr; pin_cap = 0;
+            const size_t want = std::max<size_t>(pin_bytes * 2, (size_t)256 << 10);
+            RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin), want, hipHostMallocDefault));
+            pin_cap = want;
+        }
         return RAG_OK;
     }
 };
+CandWs& cand_ws() {
+    static CandWs* w = new CandWs();  // never destroyed: no HIP calls at process exit
+    return *w;
+}
 
 }  // namespace
 
@@ -244,24 +269,36 @@ int rag_rrf(int n_rankings, const int64_t* ids, const int64_t* lens, double k_co
         for (int r = 0; r < n_rankings; ++r)
             for (int64_t j = 0; j < lens[r]; ++j) rank_of[(size_t)e++] = (int)j;
     }
+    // One device arena and one pinned host arena per process, kept across calls: a call is ONE
+    // host-to-device copy, the kernel, ONE copy back and ONE synchronisation (the per-call
+    // hipMalloc / hipFree of eight small buffers cost more than the kernel).
     hipStream_t st = lib_stream();
-    DevBuf<long long> d_ids, d_out_ids;
-    DevBuf<int> d_rank, d_first, d_n;
-    DevBuf<double> d_scores;
-    int rc;
-    if ((rc = d_ids.alloc(T)) || (rc = d_out_ids.alloc(T)) || (rc = d_rank.alloc(T)) || (rc = d_first.alloc(T)) ||
-        (rc = d_n.alloc(1)) || (rc = d_scores.alloc(T)))
-        return rc;
-    RAG_HIP(hipMemcpyAsync(d_ids.p, ids, (size_t)T * sizeof(long long), hipMemcpyHostToDevice, st));
-    RAG_HIP(hipMemcpyAsync(d_rank.p, rank_of.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
-    rrf_kernel<<<1, CAND_THREADS, 0, st>>>(d_ids.p, d_rank.p, (int)T, k_const, d_out_ids.p, d_scores.p, d_n.p,
-                                          d_first.p);
+    CandWs& ws = cand_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    const size_t ids_b = (size_t)T * sizeof(long long), rank_b = al8((size_t)T * sizeof(int));
+    const size_t in_b = ids_b + rank_b;
+    const size_t out_b = 8 + (size_t)T * (sizeof(long long) + sizeof(double));
+    const size_t first_b = al8((size_t)T * sizeof(int));
+    int rc = ws.reserve(in_b + out_b + first_b, in_b + out_b);
+    if (rc) return rc;
+    char* hin = ws.pin;
+    char* hout = ws.pin + in_b;
+    std::memcpy(hin, ids, ids_b);
+    std::memcpy(hin + ids_b, rank_of.data(), (size_t)T * sizeof(int));
+    char* din = ws.dev;
+    char* dout = ws.dev + in_b;
+    char* dfirst = dout + out_b;
+    RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
+    rrf_kernel<<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<long long*>(din), reinterpret_cast<int*>(din + ids_b), (int)T,
+                                          k_const, reinterpret_cast<long long*>(dout + 8),
+                                          reinterpret_cast<double*>(dout + 8 + ids_b), reinterpret_cast<int*>(dout),
+                                          reinterpret_cast<int*>(dfirst));
     RAG_HIP(hipGetLastError());
-    int n = 0;
-    RAG_HIP(hipMemcpyAsync(&n, d_n.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
     RAG_HIP(hipStreamSynchronize(st));
-    RAG_HIP(hipMemcpy(out_ids, d_out_ids.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
-    RAG_HIP(hipMemcpy(out_scores, d_scores.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    const int n = *reinterpret_cast<const int*>(hout);
+    std::memcpy(out_ids, hout + 8, (size_t)n * sizeof(long long));
+    std::memcpy(out_scores, hout + 8 + ids_b, (size_t)n * sizeof(double));
     *n_out = n;
     return RAG_OK;
 }
@@ -276,24 +313,36 @@ int rag_mmr(int C, int d, const float* cand, const float* q, double lambda, int 
     if (C > MMR_MAX_C)
         return fail(RAG_ERR_UNSUPPORTED, "%d candidates exceed the candidate-set limit %d", C, MMR_MAX_C);
     hipStream_t st = lib_stream();
-    DevBuf<float> d_cand, d_q, d_nrm, d_G, d_simq;
-    DevBuf<long long> d_bytes;
-    DevBuf<int> d_order, d_n;
-    int rc;
-    if ((rc = d_cand.alloc((size_t)C * d)) || (rc = d_q.alloc(d)) || (rc = d_nrm.alloc((size_t)C * d)) ||
-        (rc = d_G.alloc((size_t)C * C)) || (rc = d_simq.alloc(C)) || (rc = d_bytes.alloc(C)) ||
-        (rc = d_order.alloc(C)) || (rc = d_n.alloc(1)))
-        return rc;
-    RAG_HIP(hipMemcpyAsync(d_cand.p, cand, (size_t)C * d * sizeof(float), hipMemcpyHostToDevice, st));
-    RAG_HIP(hipMemcpyAsync(d_q.p, q, (size_t)d * sizeof(float), hipMemcpyHostToDevice, st));
-    RAG_HIP(hipMemcpyAsync(d_bytes.p, byte_len, (size_t)C * sizeof(long long), hipMemcpyHostToDevice, st));
-    mmr_kernel<<<1, CAND_THREADS, 0, st>>>(d_cand.p, d_q.p, C, d, lambda, top_k, d_bytes.p, (long long)max_bytes,
-                                          d_nrm.p, d_G.p, d_simq.p, d_order.p, d_n.p);
+    CandWs& ws = cand_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    const size_t cand_b = (size_t)C * d * sizeof(float), q_b = al8((size_t)d * sizeof(float));
+    const size_t bytes_b = (size_t)C * sizeof(long long);
+    const size_t in_b = al8(cand_b) + q_b + bytes_b;
+    const size_t out_b = 8 + al8((size_t)C * sizeof(int));
+    const size_t nrm_b = al8(cand_b), G_b = al8((size_t)C * C * sizeof(float)), simq_b = al8((size_t)C * sizeof(float));
+    int rc = ws.reserve(in_b + out_b + nrm_b + G_b + simq_b, in_b + out_b);
+    if (rc) return rc;
+    char* hin = ws.pin;
+    char* hout = ws.pin + in_b;
+    std::memcpy(hin, cand, cand_b);
+    std::memcpy(hin + al8(cand_b), q, (size_t)d * sizeof(float));
+    std::memcpy(hin + al8(cand_b) + q_b, byte_len, bytes_b);
+    char* din = ws.dev;
+    char* dout = din + in_b;
+    char* dnrm = dout + out_b;
+    char* dG = dnrm + nrm_b;
+    char* dsimq = dG + G_b;
+    RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
+    mmr_kernel<<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<float*>(din), reinterpret_cast<float*>(din + al8(cand_b)), C, d,
+                                          lambda, top_k, reinterpret_cast<long long*>(din + al8(cand_b) + q_b),
+                                          (long long)max_bytes, reinterpret_cast<float*>(dnrm),
+                                          reinterpret_cast<float*>(dG), reinterpret_cast<float*>(dsimq),
+                                          reinterpret_cast<int*>(dout + 8), reinterpret_cast<int*>(dout));
     RAG_HIP(hipGetLastError());
-    int n = 0;
-    RAG_HIP(hipMemcpyAsync(&n, d_n.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
     RAG_HIP(hipStreamSynchronize(st));
-    if (n > 0) RAG_HIP(hipMemcpy(out_order, d_order.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    const int n = *reinterpret_cast<const int*>(hout);
+    if (n > 0) std::memcpy(out_order, hout + 8, (size_t)n * sizeof(int));
     *out_n = n;
     return RAG_OK;
 }
