@@ -15,6 +15,7 @@
 #include "topk.h"
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const d
 // reference takes, vector_storage.py:180).  A buffer overflow (scores sorted by row number, say)
 // sets a flag and the list kernels above run instead; they return at once when the flag is clear.
 constexpr int SPANS = 1024;
+constexpr size_t PIN_BYTES = 32 << 10;
 constexpr int THR_CAP = 8192;
 
 __global__ __launch_bounds__(256) void span_max_kernel(const double* __restrict__ score, long long n,
@@ -446,6 +448,7 @@ struct rag_csc {
     double* out_D = nullptr; long long* out_I = nullptr; int64_t out_cap = 0;
     double* thr_ws = nullptr;   // [SPANS] span maxima + [1] threshold (threshold path of the top-k)
     int* thr_cnt = nullptr;     // [2] appended scores, overflow flag
+    char* pin = nullptr;        // 32 KiB of pinned host memory: results and rank queries of small calls
     long long* rk_rows = nullptr; unsigned long long* rk_out = nullptr;
     double* rk_skey = nullptr; long long* rk_srow = nullptr; int* rk_pos = nullptr; unsigned long long* rk_hist = nullptr;
     std::mutex mu;
@@ -528,9 +531,18 @@ int topk_scores(rag_csc* h, int k, double* D, int64_t* I, hipStream_t st) {
     else LAUNCH_TOPK(4);
 #undef LAUNCH_TOPK
     RAG_HIP(hipGetLastError());
-    RAG_HIP(hipMemcpyAsync(D, h->out_D, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, st));
-    RAG_HIP(hipMemcpyAsync(I, h->out_I, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, st));
+    // into pinned memory (true asynchronous copies); topk_finish() hands them over after the caller's
+    // synchronisation
+    if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+    RAG_HIP(hipMemcpyAsync(h->pin, h->out_D, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(h->pin + PIN_BYTES / 2, h->out_I, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, st));
     return RAG_OK;
+}
+
+void topk_finish(rag_csc* h, int k, double* D, int64_t* I) {
+    if (k <= 0) return;
+    std::memcpy(D, h->pin, (size_t)k * sizeof(double));
+    std::memcpy(I, h->pin + PIN_BYTES / 2, (size_t)k * sizeof(long long));
 }
 
 }  // namespace
@@ -593,6 +605,7 @@ void rag_csc_free(rag_csc_t* h) {
     (void)hipFree(h->out_I);
     (void)hipFree(h->thr_ws);
     (void)hipFree(h->thr_cnt);
+    if (h->pin) (void)hipHostFree(h->pin);
     (void)hipFree(h->rk_rows);
     (void)hipFree(h->rk_out);
     (void)hipFree(h->rk_skey);
@@ -645,6 +658,7 @@ int rag_bm25_scores(rag_csc_t* h, int n_qterms, const int32_t* term_ids, double*
     int rc = topk_scores(h, k, D, I, st);
     if (rc) return rc;
     RAG_HIP(hipStreamSynchronize(st));
+    topk_finish(h, k, D, I);
     return RAG_OK;
 }
 
@@ -672,6 +686,7 @@ int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const dou
     int rc = topk_scores(h, k, D, I, st);
     if (rc) return rc;
     RAG_HIP(hipStreamSynchronize(st));
+    topk_finish(h, k, D, I);
     return RAG_OK;
 }
 
@@ -686,7 +701,9 @@ int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks
     hipStream_t st = lib_stream();
     for (int q0 = 0; q0 < n_query; q0 += RANK_MAXQ) {
         const int nq = std::min(RANK_MAXQ, n_query - q0);
-        RAG_HIP(hipMemcpyAsync(h->rk_rows, rows + q0, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
+        if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+        std::memcpy(h->pin, rows + q0, (size_t)nq * sizeof(long long));
+        RAG_HIP(hipMemcpyAsync(h->rk_rows, h->pin, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
         long long nb = (h->n_rows + 2047) / 2048;
         nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
         rank_prep_kernel<<<1, RANK_MAXQ, 0, st>>>(h->score, nq, h->rk_rows, h->rk_skey, h->rk_srow, h->rk_pos, h->rk_hist);
@@ -694,8 +711,9 @@ int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks
                                                       h->rk_hist);
         rank_final_kernel<<<1, RANK_MAXQ, 0, st>>>(h->rk_hist, nq, h->rk_pos, h->rk_out);
         RAG_HIP(hipGetLastError());
-        RAG_HIP(hipMemcpyAsync(ranks + q0, h->rk_out, (size_t)nq * sizeof(long long), hipMemcpyDeviceToHost, st));
+        RAG_HIP(hipMemcpyAsync(h->pin + PIN_BYTES / 2, h->rk_out, (size_t)nq * sizeof(long long), hipMemcpyDeviceToHost, st));
         RAG_HIP(hipStreamSynchronize(st));
+        std::memcpy(ranks + q0, h->pin + PIN_BYTES / 2, (size_t)nq * sizeof(long long));
     }
     return RAG_OK;
 }
@@ -712,7 +730,9 @@ int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_s
     for (int q0 = 0; q0 < n_query; q0 += RANK_MAXQ) {
         const int nq = std::min(RANK_MAXQ, n_query - q0);
         double* dout = reinterpret_cast<double*>(h->rk_out);  // same size: RANK_MAXQ * 8 bytes
-        RAG_HIP(hipMemcpyAsync(h->rk_rows, rows + q0, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
+        if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+        std::memcpy(h->pin, rows + q0, (size_t)nq * sizeof(long long));
+        RAG_HIP(hipMemcpyAsync(h->rk_rows, h->pin, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
         gather_kernel<<<(nq + 255) / 256, 256, 0, st>>>(h->score, nq, h->rk_rows, dout);
         RAG_HIP(hipGetLastError());
         RAG_HIP(hipMemcpyAsync(out_scores + q0, dout, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, st));
