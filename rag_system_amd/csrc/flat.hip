@@ -1013,7 +1013,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             rc = wide_sample(wp, h->x, (long long)n, dch, Qw, (int)nq, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
                              st);
             if (rc) return rc;
-            kth_largest_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, wp.wpad, wp.blocks * wp.wpb, j,
+            kth_largest_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, wp.wpad, wp.blocks, j,
                                                                        h->ws_thr);
         } else if (stream) {
             rc = stream_launch(sps, h->x, (long long)n, dch, Qw, (int)nq, 1, h->metric, h->ws_key, h->ws_id, h->xnorm,

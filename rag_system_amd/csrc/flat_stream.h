@@ -36,13 +36,12 @@ struct WidePlan {
     int cap;          // filter pass: entries per query in the append buffer
     int sample_step;  // sample pass: every sample_step-th 16-row tile
     int blocks, wpb;  // grid, waves per block
-    int wpad;         // sample pass output entries per query (>= blocks*wpb, a multiple of j)
+    int wpad;         // sample pass output entries per query (= blocks)
     size_t smem;
 };
 // false if the kernel does not serve the shape (nq > 64, fewer than 16 rows, queries beyond the LDS).
-// j = sample entries wanted per query (the caller's merge reads wpad/j lists of j).
 bool wide_plan(long long n, long long nq, int dch, bool bf16, int j, int cap, int sample_step, WidePlan* p);
-// cand_*: [nq][wpad] (best score of every wave over its sampled tiles, pads = (-FLT_MAX, INT_MAX))
+// cand_*: [nq][wpad] (best score of every block over its sampled tiles; -FLT_MAX = none)
 int wide_sample(const WidePlan& p, const void* X, long long n, int dch, const void* Q, int nq, int metric,
                 float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st);
 // cand_*: [nq][cap]; counts zeroed by the caller

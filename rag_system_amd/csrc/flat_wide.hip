@@ -22,8 +22,8 @@
 // the whole chunk (8 values) at once.  The K reduction happens inside the matrix core: no fold.
 //
 // Selection: this kernel keeps no lists.  SAMPLE mode visits every 32nd 16-row tile and records
-// each wave's best score per query; the j-th largest of those wave maxima is the query's
-// threshold (equal to the j-th best sampled row unless two of the best j fall to one wave, which
+// each block's best score per query; the j-th largest of those block maxima is the query's
+// threshold (equal to the j-th best sampled row unless two of the best j fall to one block, which
 // only lowers the threshold).  FILTER mode appends every row scoring >= the threshold to the
 // query's buffer; flat.hip selects the exact top-k from the buffer and redoes a query whose
 // count left [k, cap] with the list-mode tile kernel.
@@ -53,7 +53,7 @@ __host__ __device__ constexpr int wide_nb(int NT) { return RAG_WIDE_NB_HI > 0 &&
 // 128-byte steps per row, a multiple of NB
 __host__ __device__ inline int wide_nstep(int dch, int nb) { return ((dch + 8 * nb - 1) / (8 * nb)) * nb; }
 
-// n >= 16.  cand_*: SAMPLE [nq][wpad] (one entry per wave, pads behind), FILTER [nq][cap].
+// n >= 16.  cand_*: SAMPLE [nq][wpad] (one entry per block), FILTER [nq][cap].
 template <int NT, int METRIC, bool BF, bool SAMPLE>
 __global__ __launch_bounds__(NT >= 3 ? 768 : WIDE_MAX_THREADS) void flat_wide_kernel(
     const u32x4* __restrict__ X, long long n, int dch, const u32x4* __restrict__ Q, int nq,
@@ -281,26 +281,25 @@ __global__ __launch_bounds__(NT >= 3 ? 768 : WIDE_MAX_THREADS) void flat_wide_ke
     }
 
     if (SAMPLE) {
-        // one (best score, wave) entry per wave and query; waves that saw no row write a pad
+        // one best score per BLOCK and query (the waves' maxima meet in LDS, over the query area):
+        // 256 values per query keep the threshold kernel at a few microseconds (3072 per-wave values
+        // cost it 36 us); blocks that saw no row write -FLT_MAX
+        __syncthreads();  // every wave is done with the queries
+        float* smax = reinterpret_cast<float*>(smem_raw);  // [nwv][NT*16]
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float m = mx[t];
             m = fmaxf(m, xor_lane<16>(m));
             m = fmaxf(m, xor_lane<32>(m));
-            const int q = 16 * t + lane;
-            if (lane < 16 && q < nq) {
-                const long long o = (long long)q * wpad + gw;
-                cand_key[o] = m;
-                cand_id[o] = m > -FLT_MAX ? (int)gw : IdPad<int>::v();
-            }
+            if (lane < 16) smax[wid * (NT * 16) + 16 * t + lane] = m;
         }
-        if (blockIdx.x == 0) {
-            const int npad = wpad - (int)W;
-            for (int i = tid; i < nq * npad; i += blockDim.x) {
-                const long long o = (long long)(i / npad) * wpad + W + (i % npad);
-                cand_key[o] = -FLT_MAX;
-                cand_id[o] = IdPad<int>::v();
-            }
+        __syncthreads();
+        for (int q = tid; q < NT * 16 && q < nq; q += blockDim.x) {
+            float m = -FLT_MAX;
+            for (int w = 0; w < nwv; ++w) m = fmaxf(m, smax[w * (NT * 16) + q]);
+            const long long o = (long long)q * wpad + blockIdx.x;
+            cand_key[o] = m;
+            cand_id[o] = m > -FLT_MAX ? (int)blockIdx.x : IdPad<int>::v();
         }
     }
 }
@@ -376,8 +375,8 @@ bool wide_plan(long long n, long long nq, int dch, bool bf16, int j, int cap, in
     const long long ntiles = (n + 15) / 16;
     long long blocks = std::min<long long>((long long)num_cus() * bpc, (ntiles + p->wpb - 1) / p->wpb);
     p->blocks = (int)std::max<long long>(blocks, 1);
-    const int W = p->blocks * p->wpb;
-    p->wpad = ((W + j - 1) / j) * j;
+    p->wpad = p->blocks;  // sample pass: one value per block and query
+    (void)j;
     return true;
 }
 

@@ -91,7 +91,9 @@ def test_wide_kernel_small_batches_and_launch_shapes(engine, storage):
             for wpb in (1, 4, 12):
                 _opts(lib, wide_wpb=wpb)
                 D1, I1 = _check(idx, X, Q, k, 0, storage)
-                assert np.array_equal(I0, I1) and np.array_equal(D0, D1), (nq, k, wpb)
+                # the block count changes the sample (one value per block), so a query may take the redo
+                # path of the tile kernel: same ids, scores equal up to the summation order
+                assert np.array_equal(I0, I1) and np.allclose(D0, D1, rtol=2e-6, atol=2e-7), (nq, k, wpb)
             _opts(lib, wide_wpb=0, wide_max_nq=-1, stream_max_nq=-1)
             D2, I2 = _check(idx, X, Q, k, 0, storage)
             _opts(lib, wide_max_nq=0, stream_max_nq=0)
