@@ -376,7 +376,6 @@ bool wide_plan(long long n, long long nq, int dch, bool bf16, int j, int cap, in
     long long blocks = std::min<long long>((long long)num_cus() * bpc, (ntiles + p->wpb - 1) / p->wpb);
     p->blocks = (int)std::max<long long>(blocks, 1);
     p->wpad = p->blocks;  // sample pass: one value per block and query
-    (void)j;
     return true;
 }
 
