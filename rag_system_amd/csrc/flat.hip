@@ -268,15 +268,33 @@ __global__ __launch_bounds__(MERGE_THREADS) void flat_merge_kernel(
         for (int l = threadIdx.x; l < nlists; l += MERGE_THREADS) {
             const float* lk = ck + (long long)l * k;
             const int* li = ci + (long long)l * k;
-            for (int p = 0; p < k; ++p) {
-                const float key = lk[p];
-                const int id = li[p];
-                if (!(key >= T) || id == IdPad<int>::v()) break;  // sorted: the rest is below T (or padding)
-                const int slot = atomicAdd(&n_cand, 1);
-                if (slot < SELECT_SORT_MAX) {
-                    unsigned int u = __float_as_uint(key);
-                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                    sv[slot] = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)id);
+            // four entries per round trip (independent loads): the walk down a list is a chain of
+            // dependent L2 reads otherwise, and the deepest list sets the kernel's time
+            bool more = true;
+            for (int p0 = 0; p0 < k && more; p0 += 4) {
+                float key4[4];
+                int id4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int p = p0 + e < k ? p0 + e : k - 1;
+                    key4[e] = lk[p];
+                    id4[e] = li[p];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!more || p0 + e >= k) break;
+                    const float key = key4[e];
+                    const int id = id4[e];
+                    if (!(key >= T) || id == IdPad<int>::v()) {  // sorted: the rest is below T (or padding)
+                        more = false;
+                        break;
+                    }
+                    const int slot = atomicAdd(&n_cand, 1);
+                    if (slot < SELECT_SORT_MAX) {
+                        unsigned int u = __float_as_uint(key);
+                        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                        sv[slot] = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)id);
+                    }
                 }
             }
         }

@@ -304,40 +304,41 @@ __global__ __launch_bounds__(ST_THREADS, (G * RG >= 8 ? 3 : 4)) void flat_stream
     }
 
     if (FILT) return;
-    // ---- merge the block's four wave lists through LDS (over the query area), wave 0 writes one
-    // list per real query: cand[q][block][k]
+    // ---- merge the block's four wave lists through LDS (over the query area): every wave posts its
+    // lists, wave w merges the queries q = w (mod 4) -- the tail of the kernel is a chain of sorted
+    // inserts (~0.13 us each), four times shorter when the waves share it -- and writes one list
+    // per real query: cand[q][block][k]
     __syncthreads();
     float* mk = reinterpret_cast<float*>(smem_raw);
-    int* mi = reinterpret_cast<int*>(mk + (ST_WAVES - 1) * NL * KS * 64);
-    if (wid > 0) {
+    int* mi = reinterpret_cast<int*>(mk + ST_WAVES * NL * KS * 64);
 #pragma unroll
-        for (int q = 0; q < NL; ++q)
+    for (int q = 0; q < NL; ++q)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int o = (((wid - 1) * NL + q) * KS + s) * 64 + lane;
-                mk[o] = tk[q].key[s];
-                mi[o] = tk[q].id[s];
-            }
-    }
+        for (int s = 0; s < KS; ++s) {
+            const int o = ((wid * NL + q) * KS + s) * 64 + lane;
+            mk[o] = tk[q].key[s];
+            mi[o] = tk[q].id[s];
+        }
     __syncthreads();
-    if (wid == 0) {
 #pragma unroll
-        for (int q = 0; q < NL; ++q) {
-            if (q < nq) {
-                for (int w = 0; w < ST_WAVES - 1; ++w)
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const int o = ((w * NL + q) * KS + s) * 64 + lane;
-                        wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], mk[o], mi[o], true, lane);
-                    }
-                const long long base = ((long long)q * gridDim.x + blockIdx.x) * k;
+    for (int q = 0; q < NL; ++q) {
+        if ((q & (ST_WAVES - 1)) == wid && q < nq) {
+            for (int dw = 1; dw < ST_WAVES; ++dw) {
+                const int w = (wid + dw) & (ST_WAVES - 1);
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const int p = s * 64 + lane;
-                    if (p < k) {
-                        cand_key[base + p] = tk[q].key[s];
-                        cand_id[base + p] = tk[q].id[s];
-                    }
+                    const int o = ((w * NL + q) * KS + s) * 64 + lane;
+                    // entries past a list's k-th cannot be among the best k of the union
+                    wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], mk[o], mi[o], s * 64 + lane < k, lane);
+                }
+            }
+            const long long base = ((long long)q * gridDim.x + blockIdx.x) * k;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s * 64 + lane;
+                if (p < k) {
+                    cand_key[base + p] = tk[q].key[s];
+                    cand_id[base + p] = tk[q].id[s];
                 }
             }
         }
@@ -417,7 +418,7 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     if (p->KS == 4) p->RG = 4;  // the only shape built with 256-entry lists
     const int dchp = ((dch + 16 * NB - 1) / (16 * NB)) * (16 * NB);
     const size_t qbytes = (size_t)p->G * dchp * 64;
-    const size_t mbytes = filt ? 0 : (size_t)(ST_WAVES - 1) * 4 * p->G * p->KS * 64 * 8;
+    const size_t mbytes = filt ? 0 : (size_t)ST_WAVES * 4 * p->G * p->KS * 64 * 8;
     p->smem = std::max(qbytes, mbytes);
     if (p->smem > 64 * 1024) return false;  // long rows: the tile kernel streams its queries instead
     const long long TR = 4 * p->RG;
