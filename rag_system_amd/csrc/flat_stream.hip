@@ -325,12 +325,18 @@ __global__ __launch_bounds__(ST_THREADS, (G * RG >= 8 ? 3 : 4)) void flat_stream
         if ((q & (ST_WAVES - 1)) == wid && q < nq) {
             for (int dw = 1; dw < ST_WAVES; ++dw) {
                 const int w = (wid + dw) & (ST_WAVES - 1);
+                float ck[KS];
+                int ci[KS];
+                bool cv[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const int o = ((w * NL + q) * KS + s) * 64 + lane;
-                    // entries past a list's k-th cannot be among the best k of the union
-                    wave_offer<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], mk[o], mi[o], s * 64 + lane < k, lane);
+                    ck[s] = mk[o];
+                    ci[s] = mi[o];
+                    cv[s] = s * 64 + lane < k;  // entries past a list's k-th cannot be among the best k of the union
                 }
+                // a sorted list: a handful of inserts, or one bitonic merge when many entries qualify (larger k)
+                wave_offer_chunk<float, int, KS>(tk[q], k, thr_k[q], thr_i[q], ck, ci, cv, true, lane);
             }
             const long long base = ((long long)q * gridDim.x + blockIdx.x) * k;
 #pragma unroll
