@@ -12,7 +12,7 @@ same Zipf; dense rows from the engine's generator (seed 1234), queries seed 4321
 Per query (search_engine.py:320-350 with top_k = 10):
     dense   index.search(q, 9*top_k)  -> first 3*top_k distinct documents     (rag_flat_search)
     bm25    top 3*top_k chunks                                                 (rag_bm25_scores)
-    tfidf   scores of all documents; top (top_k + |A|) + ranks of A            (rag_tfidf_scores, rag_csc_ranks)
+    tfidf   scores of all documents; top (top_k + |A|) + ranks of A            (rag_tfidf_query)
     rrf     1/(60+rank) over the three rankings                                (rag_rrf)
     mmr     top_k of the fused top 3*top_k, stored vectors as embeddings       (rag_mmr)
 Prints one JSON line.
@@ -130,8 +130,7 @@ def main():
         # the head of the ranking can reach the fused top_k (rag_system_amd/search_engine.py:245)
         uq, cnt = np.unique(tids, return_counts=True)
         cand = list(fused)
-        tI, tD = ts.top_k_from_row(uq, cnt * tfidf_idf[uq], top_k + len(cand))
-        ranks = ts.ranks(np.asarray(cand, dtype=np.int64))
+        tI, tD, ranks = ts.ranks_from_row(uq, cnt * tfidf_idf[uq], top_k + len(cand), np.asarray(cand, dtype=np.int64))
         t4 = time.perf_counter()
         for doc, rk in zip(cand, ranks):
             fused[doc] = fused[doc] + 1.0 / (60 + int(rk))

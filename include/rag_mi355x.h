@@ -174,6 +174,13 @@ int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks
  * search_engine.py:286 builds a dict over ALL documents, of which the fusion
  * (:301-311) only reads the candidates' entries. */
 int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_scores);
+/* rag_tfidf_scores (top-k only) + rag_csc_ranks + rag_csc_gather in ONE call and one
+ * synchronisation: what a hybrid query needs from the TF-IDF ranking (search_engine.py:284-286 scores
+ * and :332-336 ranks ALL documents; the fusions at :301-311 / :338-345 read the head of the ranking and
+ * the candidates' own entries).  n_query <= 1024; ranks / row_scores may be NULL.  Identical outputs
+ * to the three calls. */
+int rag_tfidf_query(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights, int k, double* D,
+                    int64_t* I, int n_query, const int64_t* rows, int64_t* ranks, double* row_scores);
 
 /* ---- candidate-set kernels -------------------------------------------- */
 

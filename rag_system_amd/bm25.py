@@ -78,6 +78,21 @@ class _HipCsc:
         _lib.check(self._lib.rag_csc_gather(self._h, len(r), _lib.ptr(r), _lib.ptr(out)), self._lib)
         return out
 
+    MAX_QUERY_ROWS = 1024
+
+    def tfidf_query(self, term_ids, weights, k, rows, want_scores=True):
+        """(D, I, ranks, row_scores): tfidf_scores(k) + ranks(rows) + gather(rows) in one call
+        (rag_tfidf_query; len(rows) <= MAX_QUERY_ROWS).  row_scores is None unless wanted."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        _, D, I = self._out(False, k)
+        ranks = np.empty(len(r), dtype=np.int64)
+        sc = np.empty(len(r), dtype=np.float64) if want_scores else None
+        _lib.check(self._lib.rag_tfidf_query(self._h, len(t), _lib.ptr(t), _lib.ptr(w), int(k), _lib.ptr(D), _lib.ptr(I),
+                                             len(r), _lib.ptr(r), _lib.ptr(ranks), _lib.ptr(sc)), self._lib)
+        return D[:k], I[:k], ranks, sc
+
 
 _csc_factory = _HipCsc
 

@@ -149,7 +149,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void dense_topk_merge_kernel(const d
 // reference takes, vector_storage.py:180).  A buffer overflow (scores sorted by row number, say)
 // sets a flag and the list kernels above run instead; they return at once when the flag is clear.
 constexpr int SPANS = 1024;
-constexpr size_t PIN_BYTES = 32 << 10;
+constexpr size_t PIN_BYTES = 64 << 10;
+// rag_tfidf_query keeps the top-k at [0, 2K) / [32K, 34K) like every top-k call and adds:
+constexpr size_t PIN_Q_ROWS = 4 << 10, PIN_Q_RANKS = 36 << 10, PIN_Q_SCORES = 44 << 10;  // 8 KiB each (RANK_MAXQ x 8)
 constexpr int THR_CAP = 8192;
 
 __global__ __launch_bounds__(256) void span_max_kernel(const double* __restrict__ score, long long n,
@@ -448,7 +450,8 @@ struct rag_csc {
     double* out_D = nullptr; long long* out_I = nullptr; int64_t out_cap = 0;
     double* thr_ws = nullptr;   // [SPANS] span maxima + [1] threshold (threshold path of the top-k)
     int* thr_cnt = nullptr;     // [2] appended scores, overflow flag
-    char* pin = nullptr;        // 32 KiB of pinned host memory: results and rank queries of small calls
+    char* pin = nullptr;        // 64 KiB of pinned host memory: results and rank queries of small calls
+    double* rk_gather = nullptr;  // rag_tfidf_query: scores of the queried rows
     long long* rk_rows = nullptr; unsigned long long* rk_out = nullptr;
     double* rk_skey = nullptr; long long* rk_srow = nullptr; int* rk_pos = nullptr; unsigned long long* rk_hist = nullptr;
     std::mutex mu;
@@ -612,6 +615,7 @@ void rag_csc_free(rag_csc_t* h) {
     (void)hipFree(h->rk_srow);
     (void)hipFree(h->rk_pos);
     (void)hipFree(h->rk_hist);
+    (void)hipFree(h->rk_gather);
     delete h;
 }
 
@@ -687,6 +691,63 @@ int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const dou
     if (rc) return rc;
     RAG_HIP(hipStreamSynchronize(st));
     topk_finish(h, k, D, I);
+    return RAG_OK;
+}
+
+int rag_tfidf_query(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights, int k, double* D,
+                    int64_t* I, int n_query, const int64_t* rows, int64_t* ranks, double* row_scores) {
+    RAG_REQUIRE_INIT();
+    if (!h || nnz_q < 0 || (nnz_q > 0 && (!term_ids || !q_weights)) || k < 0 || (k > 0 && (!D || !I)) || n_query < 0 ||
+        (n_query > 0 && !rows))
+        return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    if (n_query > RANK_MAXQ)
+        return fail(RAG_ERR_INVALID_ARG, "rag_tfidf_query: n_query=%d beyond %d (use rag_csc_ranks / rag_csc_gather)",
+                    n_query, RANK_MAXQ);
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int i = 0; i < nnz_q; ++i)
+        if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
+            return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
+    for (int i = 0; i < n_query; ++i)
+        if (rows[i] < 0 || rows[i] >= h->n_rows)
+            return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)rows[i], (long long)h->n_rows);
+    hipStream_t st = lib_stream();
+    if (h->n_rows > 0) RAG_HIP(hipMemsetAsync(h->score, 0, (size_t)h->n_rows * sizeof(double), st));
+    for (int i = 0; i < nnz_q; ++i) {
+        const int t = term_ids[i];
+        const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
+        if (b1 <= b0) continue;
+        tfidf_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, q_weights[i], h->score);
+    }
+    RAG_HIP(hipGetLastError());
+    h->have_scores = true;
+    int rc = topk_scores(h, k, D, I, st);
+    if (rc) return rc;
+    const bool want_ranks = n_query > 0 && ranks != nullptr, want_scores = n_query > 0 && row_scores != nullptr;
+    if (want_ranks || want_scores) {
+        if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+        std::memcpy(h->pin + PIN_Q_ROWS, rows, (size_t)n_query * sizeof(long long));
+        RAG_HIP(hipMemcpyAsync(h->rk_rows, h->pin + PIN_Q_ROWS, (size_t)n_query * sizeof(long long), hipMemcpyHostToDevice, st));
+    }
+    if (want_ranks) {
+        long long nb = (h->n_rows + 2047) / 2048;
+        nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
+        rank_prep_kernel<<<1, RANK_MAXQ, 0, st>>>(h->score, n_query, h->rk_rows, h->rk_skey, h->rk_srow, h->rk_pos, h->rk_hist);
+        rank_hist_kernel<<<(unsigned)nb, 256, 0, st>>>(h->score, (long long)h->n_rows, n_query, h->rk_skey, h->rk_srow,
+                                                      h->rk_hist);
+        rank_final_kernel<<<1, RANK_MAXQ, 0, st>>>(h->rk_hist, n_query, h->rk_pos, h->rk_out);
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipMemcpyAsync(h->pin + PIN_Q_RANKS, h->rk_out, (size_t)n_query * sizeof(long long), hipMemcpyDeviceToHost, st));
+    }
+    if (want_scores) {
+        if (!h->rk_gather) RAG_HIP(hipMalloc(&h->rk_gather, RANK_MAXQ * sizeof(double)));
+        gather_kernel<<<(n_query + 255) / 256, 256, 0, st>>>(h->score, n_query, h->rk_rows, h->rk_gather);
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipMemcpyAsync(h->pin + PIN_Q_SCORES, h->rk_gather, (size_t)n_query * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    RAG_HIP(hipStreamSynchronize(st));
+    topk_finish(h, k, D, I);
+    if (want_ranks) std::memcpy(ranks, h->pin + PIN_Q_RANKS, (size_t)n_query * sizeof(long long));
+    if (want_scores) std::memcpy(row_scores, h->pin + PIN_Q_SCORES, (size_t)n_query * sizeof(double));
     return RAG_OK;
 }
 

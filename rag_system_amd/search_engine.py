@@ -219,10 +219,8 @@ class SearchEngine:
             pos = (doc_ids, {d: i for i, d in enumerate(doc_ids)})
             self.vector_storage._tfidf_pos = pos
         pos = pos[1]
-        top_idx, top_sc = scorer.top_k(query, min(n_extra, len(doc_ids)))
         rows = [pos[d] for d in cand_doc_ids if d in pos]
-        ranks = scorer.ranks(rows) if rows else []
-        scores = scorer.gather(rows) if rows else []
+        top_idx, top_sc, ranks, scores = scorer.query(query, min(n_extra, len(doc_ids)), rows)
         cand = {doc_ids[r]: (int(rk), float(sc)) for r, rk, sc in zip(rows, ranks, scores)}
         return [doc_ids[int(i)] for i in top_idx], [float(s) for s in top_sc], cand
 

@@ -84,3 +84,27 @@ class TfidfScorer:
     def gather(self, doc_indices):
         """Scores of the given documents from the LAST scores()/top_k() call."""
         return self._csc.gather(doc_indices)
+
+    def ranks_from_row(self, indices, data, k, doc_indices):
+        """(top_idx, top_scores, ranks): top_k_from_row(k) + ranks(doc_indices) in one engine call."""
+        from scipy.sparse import csr_matrix
+        indices = np.asarray(indices, dtype=np.int32)
+        qv = csr_matrix((np.asarray(data, dtype=np.float64), indices, np.array([0, len(indices)], dtype=np.int32)),
+                        shape=(1, self.n_terms))
+        t, w = self._normalized(qv)
+        D, I, ranks, _ = self._csc.tfidf_query(t, w, min(int(k), self.n_docs), doc_indices, want_scores=False)
+        return I, D, ranks
+
+    def query(self, query, k, doc_indices):
+        """(top_idx, top_scores, ranks, scores) = top_k(query, k) + ranks(doc_indices) +
+        gather(doc_indices), in one engine call when the backend has one (rag_tfidf_query)."""
+        k = min(int(k), self.n_docs)
+        fused = getattr(self._csc, "tfidf_query", None)
+        if (fused is None or k > _bm25.BM25Okapi.MAX_FUSED_K or not len(doc_indices)
+                or len(doc_indices) > getattr(self._csc, "MAX_QUERY_ROWS", 0)):
+            I, D = self.top_k(query, k)
+            has = len(doc_indices) > 0
+            return I, D, (self.ranks(doc_indices) if has else []), (self.gather(doc_indices) if has else [])
+        t, w = self._query(query)
+        D, I, ranks, sc = fused(t, w, k, doc_indices)
+        return I, D, ranks, sc

@@ -115,6 +115,15 @@ def test_tfidf_live_sklearn_topk_and_ranks(engine):
         ranks_ref = osp.stable_ranks_desc(exp)
         rows = np.array([0, 2, 40, 41, 1199, 600, 2], dtype=np.int64)
         assert sc.ranks(rows).tolist() == ranks_ref[rows].tolist()
+        # the one-call form (rag_tfidf_query) returns what the three calls return
+        for k in (0, 10, 70):
+            ids, s, rk, rs = sc.query(q, k, rows)
+            order = osp.stable_topk_desc(exp, k)
+            assert list(ids) == order and np.array_equal(_bits(np.asarray(s)), _bits(exp[order]))
+            assert list(rk) == ranks_ref[rows].tolist()
+            assert np.array_equal(_bits(np.asarray(rs)), _bits(exp[rows]))
+        ids, s, rk, rs = sc.query(q, 5, [])
+        assert list(ids) == osp.stable_topk_desc(exp, 5) and len(rk) == 0 and len(rs) == 0
 
 
 def test_sparse_argument_validation(engine):
@@ -194,6 +203,17 @@ def test_csc_large_single_term_and_many_rows(engine):
     full_rank = np.empty(n, dtype=np.int64)
     full_rank[np.lexsort((np.arange(n), -exp))] = np.arange(n)
     assert h.ranks(q).tolist() == full_rank[q].tolist()
+    # one call, 1024 queried rows (its limit), ranks only / ranks and scores
+    q2 = np.concatenate([q, rng.integers(0, n, 1019)]).astype(np.int64)
+    D2, I2, rk, rs = h.tfidf_query([0, 1], [0.5, 0.25], 100, q2)
+    assert I2.tolist() == order.tolist() and np.array_equal(D2, exp[order])
+    assert rk.tolist() == full_rank[q2].tolist() and np.array_equal(rs, exp[q2])
+    D3, I3, rk3, rs3 = h.tfidf_query([0, 1], [0.5, 0.25], 10, q2[:7], want_scores=False)
+    assert rs3 is None and rk3.tolist() == full_rank[q2[:7]].tolist() and I3.tolist() == order[:10].tolist()
+    with pytest.raises(ValueError):
+        h.tfidf_query([0], [1.0], 10, np.zeros(1025, dtype=np.int64))
+    with pytest.raises(ValueError):
+        h.tfidf_query([0], [1.0], 10, np.array([n], dtype=np.int64))
 
 
 def _topk_of_vector(h_cache, scores, k):
