@@ -16,6 +16,10 @@ Per query (search_engine.py:320-350 with top_k = 10):
     rrf     1/(60+rank) over the three rankings                                (rag_rrf)
     mmr     top_k of the fused top 3*top_k, stored vectors as embeddings       (rag_mmr)
 Prints one JSON line.
+
+oracle/ is imported here in the two roles bench.py has for it and no other: as the CHECKER of the
+recorded results, after the timed region, and as the CPU baseline leg (--no-cpu skips it).  Nothing
+that is timed as the engine's work touches it.
 """
 import argparse
 import json
