@@ -9,6 +9,7 @@ struct StreamPlan {
     int G;          // query groups of 4 (the kernel serves nq <= 4*G queries)
     int RG;         // row groups of 4 per wave tile
     int KS;         // 64-entry register slots per top-k list (list mode)
+    int NB;         // segment buffers per wave (ring depth)
     bool bf16;      // rows and queries are bfloat16
     bool filt;      // filter mode: fixed per-query thresholds + append buffers instead of lists
     int cap;        // filter mode: entries per query in the append buffer

@@ -30,6 +30,12 @@
 #ifndef RAG_STREAM_NB
 #define RAG_STREAM_NB 3  // segment buffers per wave: NB-1 segments in flight ahead of the one being multiplied
 #endif
+// The light shapes (up to 4 queries, k <= 64, or filter mode) are also built with a ring of 2 and run
+// ONE block per CU: with little work per segment a wave only waits for its loads, and 4 waves x one
+// or two 4 KiB segments in flight per CU is where HBM delivers most -- 10M x 384, nq = 1: 7.23 TB/s
+// against 7.10 with 16 waves x 3 buffers; 8 or 16 KiB more in flight per wave only queue in the
+// memory system (benchmarks/run_stream_variants.sh, run_nb2_matrix.sh).  Shapes with more work per
+// row (8+ queries, long lists) need the other waves of a SIMD to cover it and keep the deep ring.
 
 namespace rag {
 namespace {
@@ -38,9 +44,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ST_THREADS = 256;
+#ifndef RAG_STREAM_THREADS
+#define RAG_STREAM_THREADS 256
+#endif
+constexpr int ST_THREADS = RAG_STREAM_THREADS;
 constexpr int ST_WAVES = ST_THREADS / 64;
-constexpr int NB = RAG_STREAM_NB;
+constexpr int NB_DEFAULT = RAG_STREAM_NB;
+constexpr int NB_LIGHT = 2;
 
 // Sum N = 4*RG per-lane values over lane bits 5..2 (the 16 k slices), halving the value count
 // at each step while it lasts: afterwards v[0] of lane l is the total of item (l >> (6-log2 N)).
@@ -81,8 +91,11 @@ __device__ __forceinline__ void fold_slices(float (&v)[N], int lane) {
 
 // n >= 4*RG (the host plans the tile kernel for smaller shards): the last, partial wave tile is
 // the window [n - 4*RG, n) with the rows below the tile's own first row masked out.
-template <int G, int RG, int KS, int METRIC, bool BF, bool FILT>
-__global__ __launch_bounds__(ST_THREADS, (G * RG >= 8 ? 3 : 4)) void flat_stream_kernel(
+#ifndef RAG_STREAM_MINB
+#define RAG_STREAM_MINB (G * RG >= 8 ? 3 : 4)  // blocks per CU the register budget must admit
+#endif
+template <int G, int RG, int KS, int METRIC, bool BF, bool FILT, int NB>
+__global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kernel(
     const u32x4* __restrict__ X, long long n, int dch, const u32x4* __restrict__ Q, int nq, int k,
     float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
     const float* __restrict__ qnorm, long long tile_step, const int* __restrict__ run_flag,
@@ -364,10 +377,10 @@ struct Args {
     hipStream_t st;
 };
 
-template <int G, int RG, int KS, bool BF, bool FILT>
-int launch(const StreamPlan& p, const Args& a) {
-    auto fn = a.metric == RAG_METRIC_IP ? flat_stream_kernel<G, RG, KS, RAG_METRIC_IP, BF, FILT>
-                                        : flat_stream_kernel<G, RG, KS, RAG_METRIC_L2, BF, FILT>;
+template <int G, int RG, int KS, bool BF, bool FILT, int NB>
+int launch_nb(const StreamPlan& p, const Args& a) {
+    auto fn = a.metric == RAG_METRIC_IP ? flat_stream_kernel<G, RG, KS, RAG_METRIC_IP, BF, FILT, NB>
+                                        : flat_stream_kernel<G, RG, KS, RAG_METRIC_L2, BF, FILT, NB>;
     if (p.smem > 48 * 1024)
         RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p.smem));
@@ -376,6 +389,14 @@ int launch(const StreamPlan& p, const Args& a) {
         a.cand_id, a.xnorm, a.qnorm, (long long)p.tile_step, a.run_flag, a.thr_q, a.counts, p.cap);
     RAG_HIP(hipGetLastError());
     return RAG_OK;
+}
+
+template <int G, int RG, int KS, bool BF, bool FILT>
+int launch(const StreamPlan& p, const Args& a) {
+    if constexpr (G == 1 && RG == 4 && KS == 1) {  // the shapes stream_plan() may give the short ring
+        if (p.NB == NB_LIGHT) return launch_nb<G, RG, KS, BF, FILT, NB_LIGHT>(p, a);
+    }
+    return launch_nb<G, RG, KS, BF, FILT, NB_DEFAULT>(p, a);
 }
 
 template <int G, int RG, bool BF>
@@ -422,6 +443,16 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     p->RG = opt.stream_rg == 2 || opt.stream_rg == 4 ? (int)opt.stream_rg : (p->G == 4 ? 2 : 4);
     if (p->G == 4) p->RG = 2;
     if (p->KS == 4) p->RG = 4;  // the only shape built with 256-entry lists
+    // ring depth: see NB_LIGHT above ("stream_nb": 2 / 3 force one where both are built)
+    const bool light_built = p->G == 1 && p->RG == 4 && (filt || p->KS == 1);  // filter mode is built with KS = 1
+    // measured (benchmarks/run_nb_k.sh, 10M x 384): nq 1: k 10 / 32 / 64 = 2.142 / 2.157 / 2.175 ms against
+    // 2.191-2.196; nq 4: k 10 2.173 against 2.197, k 20 a tie, k 32 and nq 3 k 64 lose 1.5-3 % (the one
+    // wave of a SIMD also carries every list insert); filter pass nq 4 k 100: 2.318 against 2.354.
+    // 1M rows: nq 1 k 10 0.240 against 0.246 ms; nq 4 k 30 0.307 against 0.265 (list warm-up)
+    const long long list_load = nq * (long long)k;
+    const bool light_auto = filt || (list_load <= 64 && (n >= (4LL << 20) || list_load <= 16));
+    p->NB = light_built && (opt.stream_nb == NB_LIGHT || (opt.stream_nb == 0 && light_auto)) ? NB_LIGHT : NB_DEFAULT;
+    const int NB = p->NB;
     const int dchp = ((dch + 16 * NB - 1) / (16 * NB)) * (16 * NB);
     const size_t qbytes = (size_t)p->G * dchp * 64;
     const size_t mbytes = filt ? 0 : (size_t)ST_WAVES * 4 * p->G * p->KS * 64 * 8;
@@ -429,7 +460,9 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     if (p->smem > 64 * 1024) return false;  // long rows: the tile kernel streams its queries instead
     const long long TR = 4 * p->RG;
     const long long ntiles = ((n + TR - 1) / TR + p->tile_step - 1) / p->tile_step;
-    const long long bpc = opt.stream_bpc > 0 ? opt.stream_bpc : (p->G * p->RG >= 8 ? 3 : 4);  // = the kernel's launch bound
+    const long long bpc = opt.stream_bpc > 0 ? opt.stream_bpc
+                          : p->NB == NB_LIGHT ? 1
+                                              : (p->G * p->RG >= 8 ? 3 : 4);  // = the kernel's launch bound
     long long blocks = std::min<long long>((long long)num_cus() * bpc, (ntiles + ST_WAVES - 1) / ST_WAVES);
     p->blocks = (int)std::max<long long>(blocks, 1);
     p->nlists = p->blocks;

@@ -98,6 +98,45 @@ def test_stream_kernel_agrees_with_tile_kernel_and_tile_heights(engine, storage)
 
 
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_short_ring_shapes_match_oracle_and_deep_ring(engine, metric, storage):
+    """The light shapes (up to 4 queries, k <= 64) are built with a ring of 2 segment buffers and
+    run one block per CU (option stream_nb: 0 = by rule, 2 / 3 forced): same ids as the ring of 3,
+    for rows that end inside a segment, an odd number of segments, and several blocks per CU."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(4242 + metric)
+    try:
+        for n, d in [(16, 384), (300, 64), (5003, 37), (20_011, 384), (9_000, 200), (3001, 1000), (70_001, 72)]:
+            X = _rand_unit(rng, n, d)
+            if n > 100:
+                X[n // 2] = X[3]
+                X[n - 1] = X[3]
+            idx = faiss.IndexFlat(d, metric, storage=storage)
+            idx.add(X)
+            for nq, k in [(1, 10), (1, 64), (2, 33), (3, 1), (4, 16), (4, 64)]:
+                Q = _rand_unit(rng, nq, d)
+                Q[0] = X[min(3, n - 1)]
+                _opts(lib, stream_nb=3, stream_bpc=0)
+                D3, I3 = _check(idx, X, Q, k, metric, storage)
+                for bpc in (0, 1, 3):
+                    _opts(lib, stream_nb=2, stream_bpc=bpc)
+                    D2, I2 = _check(idx, X, Q, k, metric, storage)
+                    assert np.array_equal(I2, I3), (n, d, nq, k, bpc)
+                    assert np.allclose(D2, D3, rtol=2e-6, atol=2e-7)
+        # filter mode with the short ring in the filter pass and in the sample pass
+        _opts(lib, stream_nb=2, stream_bpc=0, mfma_filter_k=1, mfma_filter_min_rows=1)
+        X = _rand_unit(rng, 70_001, 72)
+        idx = faiss.IndexFlat(72, metric, storage=storage)
+        idx.add(X)
+        for nq, k in [(1, 10), (4, 100), (3, 50)]:
+            Q = _rand_unit(rng, nq, 72)
+            _check(idx, X, Q, k, metric, storage)
+    finally:
+        _opts(lib, stream_nb=0, stream_bpc=0, mfma_filter_k=0, mfma_filter_min_rows=1 << 19)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_filter_mode_matches_oracle(engine, storage):
     """Sample pass and filter pass by the stream kernel (redo by the tile kernel), forced on
     small inputs, including row orders that defeat the 1-in-32 sample."""
