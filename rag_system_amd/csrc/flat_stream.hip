@@ -462,7 +462,10 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     const long long ntiles = ((n + TR - 1) / TR + p->tile_step - 1) / p->tile_step;
     const long long bpc = opt.stream_bpc > 0 ? opt.stream_bpc
                           : p->NB == NB_LIGHT ? 1
-                                              : (p->G * p->RG >= 8 ? 3 : 4);  // = the kernel's launch bound
+                          // long lists for one or two queries: two blocks per CU (nq 1, k 100: 2.195 against
+                          // 2.207 ms with four; 1M rows, k 90: 0.252 against 0.263; benchmarks/run_less_inflight.sh)
+                          : (p->G == 1 && nq <= 2) ? 2
+                                                   : (p->G * p->RG >= 8 ? 3 : 4);  // = the kernel's launch bound
     long long blocks = std::min<long long>((long long)num_cus() * bpc, (ntiles + ST_WAVES - 1) / ST_WAVES);
     p->blocks = (int)std::max<long long>(blocks, 1);
     p->nlists = p->blocks;
