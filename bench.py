@@ -4,14 +4,23 @@
     python bench.py [--gpus N --steps K --warmup W] [--nq 1] [--rows 10000000 --dim 384 --k 10]
 
 One step = one pass of the hot path over one query batch: rag_flat_search_dev (pad + scan +
-merge kernels) [+ RCCL all-gather of the per-rank top-k + rag_topk_merge_dev when N > 1] +
-copy of the (nq x k) result to the host + stream synchronise.  The corpus is resident in
-HBM before the timed region; the query batch (nq*d*4 bytes) is resident too.
+merge kernels) [+ RCCL all-gather of the per-rank top-k + rag_topk_merge_strided_dev when N > 1],
+the (nq x k) result on the host, one stream synchronise -- every step, so a step is also the
+latency of one query batch.  Everything is enqueued on ONE explicit (non-default) stream.  The
+result reaches the host either because the last kernel writes it straight into pinned host
+memory (`--out pinned`, the default: no copy) or by one D2H copy on the same stream
+(`--out device`).  The corpus is resident in HBM before the timed region; the query batch
+(nq*d*4 bytes) is resident too.
 
 N > 1: launched by torch.distributed.run, one rank per GPU.  STRONG scaling: the same
 10M-row corpus is row-sharded over the ranks (rank r holds rows [r*ceil(n/N), ...)), every
 rank scans its shard for the same queries, candidates are exchanged with one all-gather
-(the path's only exchange step) and merged on every rank.
+(the path's only exchange step) and merged on every rank.  The line then also
+carries `stages` (per-rank scan / all-gather / merge milliseconds) and a `c4` leg: BASELINE
+config 4, 100M x 768 fp32 split over the ranks (north_star's scaling workload).
+
+N = 1 appends time-bounded legs for the other BASELINE configs beside the headline `value`
+(`batch1024`, `c2`, `c3`, `c4_shard`, `c5`), each with its own roofline; `--no-legs` skips them.
 
 The JSON line carries `roofline` (scan kernel, measured live with HIP events on the stream
 the kernel runs on) and `cpu_baseline` (oracle/flat_ref.c:flat_search_cpu_baseline, a
@@ -31,6 +40,13 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = vector rate
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
+T0 = time.perf_counter()
+
+
+def log(msg):
+    if os.environ.get("RANK", "0") == "0":
+        print("[bench %6.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -44,12 +60,18 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
                     help="row storage (bf16: BASELINE config 3; rows and queries rounded to bfloat16)")
+    ap.add_argument("--out", choices=["pinned", "device"], default="pinned",
+                    help="where the last kernel writes the (nq x k) result: pinned host memory (no copy) "
+                         "or HBM followed by one D2H copy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (A/B runs)")
     ap.add_argument("--dump-result", default=None, help="write the last step's (D, I) to this .npz (rank 0)")
     ap.add_argument("--no-batch-leg", action="store_true",
                     help="skip the extra batch-1024 measurement reported beside the batch-1 headline")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary-config legs (c2, c3, c4, c5)")
+    ap.add_argument("--legs", default="c2,c3,c4_shard,c5", help="which secondary legs to run at N=1")
+    ap.add_argument("--c4-rows", type=int, default=100_000_000, help="rows of the N>1 c4 leg (x 768 fp32)")
     return ap.parse_args()
 
 
@@ -88,6 +110,141 @@ def cpu_baseline(args, Q):
     return out
 
 
+def kernel_name(nq, k, n_local, bf):
+    """Which kernel makes the timed pass (the engine's dispatch, csrc/flat.hip search_device; the
+    rocprofv3 summaries under profiles/ show the same names)."""
+    if k > 128:
+        return "flat_stream_kernel (256-entry lists)" if nq <= 4 else "flat_scan_kernel (pairs)"
+    if nq <= 8 or (nq <= 16 and n_local < (1 << 19)):
+        return "flat_stream_kernel"
+    if nq <= 192 and n_local >= (1 << 19) and (nq <= 64 or not bf):
+        return "flat_wide_kernel (sample + filter passes%s)" % (
+            "" if nq <= 64 else ", %d query chunks" % ((nq + 63) // 64))
+    return "flat_mfma_kernel"
+
+
+def roofline(nq, k, n_local, d, bf, n_launch, scan_ms, bytes_per_launch, steps):
+    avg_ms = scan_ms / max(n_launch, 1)
+    launches_per_step = n_launch / float(max(steps, 1))
+    mfma_peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
+    esz = 2 if bf else 4
+    # arithmetic intensity 2*nq/esz flop per byte against the ridge peak_flops / peak_bytes
+    hbm_bound = 2.0 * nq / esz <= mfma_peak * 1e3 / HBM_PEAK_GBS
+    if hbm_bound:
+        ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None}
+    else:
+        flops = 2.0 * nq * n_local * d / (launches_per_step if launches_per_step else 1.0)
+        ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach / mfma_peak,
+                "traffic": None}
+    roof.update({"kernel": kernel_name(nq, k, n_local, bf), "avg_launch_ms": avg_ms, "launches": n_launch,
+                 "algorithmic_bytes_per_launch": bytes_per_launch})
+    return roof
+
+
+class Runner:
+    """One resident index + one query batch + the step function, on one explicit stream."""
+
+    def __init__(self, env, rows_total, d, k, nq, storage, seed, out_mode, index=None):
+        import torch
+        from rag_system_amd import faiss_compat as faiss
+        from rag_system_amd.sharded import ShardedFlatSearcher
+        self.env, self.k, self.nq, self.d = env, k, nq, d
+        self.rows_total = rows_total
+        world, rank = env["world"], env["rank"]
+        per = (rows_total + world - 1) // world
+        self.base = rank * per
+        self.n_local = max(0, min(rows_total, self.base + per) - self.base)
+        self.bf = storage == "bf16"
+        if index is None:
+            index = faiss.IndexFlat(d, faiss.METRIC_INNER_PRODUCT, storage=storage)
+            index._b.reserve(self.n_local)
+            index._b.add_synthetic(self.n_local, seed, self.base)
+        self.index = index      # resident corpus (shared between runners of different batch sizes)
+        qgen = faiss.IndexFlatIP(d)
+        qgen._b.add_synthetic(nq, 4321, 0)
+        self.Q = qgen.reconstruct_n(0, nq)
+        del qgen
+        dev, stream = env["dev"], env["stream"]
+        self.stream = stream
+        with torch.cuda.stream(stream):
+            self.q_dev = torch.from_numpy(self.Q).to(dev)
+        words = ShardedFlatSearcher.words(nq, k)
+        self.out_host = torch.zeros(words, dtype=torch.int64).pin_memory()   # ids + scores
+        self.out_mode = out_mode
+
+        def local_search(q, kk, D_loc, I_loc, st):
+            self.index._b.search_dev(nq, q.data_ptr(), kk, D_loc.data_ptr(), I_loc.data_ptr(), self.base, st)
+
+        self.searcher = ShardedFlatSearcher(local_search, 0, nq, k, dev, stream=stream,
+                                            out=self.out_host if out_mode == "pinned" else None)
+        self.D_host, self.I_host = self.searcher.unpack(self.out_host)
+
+    def step(self):
+        import torch
+        self.searcher.search(self.q_dev)
+        if self.out_mode != "pinned":
+            with torch.cuda.stream(self.stream):
+                self.out_host.copy_(self.searcher.out_packed, non_blocking=True)
+        self.stream.synchronize()
+
+    def fence(self):
+        import torch
+        import torch.distributed as dist
+        if self.env["world"] > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """-> (elapsed seconds [max over ranks], n scan launches, their total ms, bytes per launch)."""
+        import torch
+        import torch.distributed as dist
+        for _ in range(warmup):
+            self.step()
+        self.index._b.profiling(True)
+        self.index._b.timing()  # drop anything recorded so far
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        self.index._b.profiling(False)
+        n_launch, scan_ms, bpl = self.index._b.timing()
+        if self.env["world"] > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.env["dev"])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, n_launch, scan_ms, bpl
+
+    def check_plausible(self):
+        Dn, In = self.D_host.numpy(), self.I_host.numpy()
+        assert ((In >= 0) & (In < self.rows_total)).all(), "ids out of range"
+        assert (Dn[:, :-1] >= Dn[:, 1:]).all(), "scores not sorted best-first"
+        return Dn, In
+
+    def stages(self, steps=20):
+        """Per-rank stage times gathered on rank 0 (list indexed by rank)."""
+        import torch.distributed as dist
+        mine = self.searcher.time_stages(self.q_dev, steps)
+        if self.env["world"] == 1:
+            return [mine]
+        allr = [None] * self.env["world"]
+        dist.all_gather_object(allr, mine)
+        return allr
+
+    def leg(self, name, steps, warmup, workload):
+        el, nl, ms, bpl = self.timed(steps, warmup)
+        out = {"workload": workload, "nq": self.nq, "k": self.k, "value": self.nq * steps / el, "unit": "QPS",
+               "steps": steps, "ms_per_step": el / steps * 1e3,
+               "roofline": roofline(self.nq, self.k, self.n_local, self.d, self.bf, nl, ms, bpl, steps)}
+        if self.env["rank"] == 0:
+            self.check_plausible()
+        return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -102,15 +259,14 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from rag_system_amd import _lib, faiss_compat as faiss
-    from rag_system_amd.sharded import ShardedFlatSearcher
+    from rag_system_amd import _lib
 
     # RAG_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo as the transport -- a functional
     # rehearsal of the N > 1 path on a one-GPU box (never a performance number)
     rehearsal = os.environ.get("RAG_BENCH_REHEARSAL") == "1"
     if rehearsal:
         import faulthandler
-        faulthandler.dump_traceback_later(60, exit=True)   # a stuck rehearsal names its line
+        faulthandler.dump_traceback_later(int(os.environ.get("RAG_BENCH_REHEARSAL_TIMEOUT", "90")), exit=True)
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -125,147 +281,43 @@ def main():
         name, val = o.split("=")
         _lib.check(lib.rag_set_option(name.encode(), int(val)))
 
+    env = {"world": world, "rank": rank, "dev": dev, "stream": torch.cuda.Stream(dev)}
     n, d, k, nq = args.rows, args.dim, args.k, args.nq
-    per = (n + world - 1) // world
-    base = rank * per
-    n_local = max(0, min(n, base + per) - base)
+    bf = args.storage == "bf16"
 
-    index = faiss.IndexFlat(d, faiss.METRIC_INNER_PRODUCT, storage=args.storage)
-    index._b.reserve(n_local)
-    index._b.add_synthetic(n_local, args.seed, base)
-    qgen = faiss.IndexFlatIP(d)
-    qgen._b.add_synthetic(nq, 4321, 0)
-    Q = qgen.reconstruct_n(0, nq)
-    del qgen
-
-    q_dev = torch.from_numpy(Q).to(dev)
-    stream = torch.cuda.current_stream()
-    st = stream.cuda_stream
-
-    def local_search(q, kk, D_loc, I_loc):
-        index._b.search_dev(nq, q.data_ptr(), kk, D_loc.data_ptr(), I_loc.data_ptr(), base, st)
-
-    searcher = ShardedFlatSearcher(local_search, 0, nq, k, dev, stream=st)
-    out_host = torch.empty_like(searcher.out_packed, device="cpu").pin_memory()  # ids + scores, one copy
-    D_host, I_host = searcher.unpack(out_host)
-
-    def step():
-        searcher.search(q_dev)
-        out_host.copy_(searcher.out_packed, non_blocking=True)
-        stream.synchronize()
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    index._b.profiling(True)
-    index._b.timing()  # drop anything recorded so far
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    index._b.profiling(False)
-    n_launch, scan_ms, bytes_per_launch = index._b.timing()
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    log("building the %d x %d %s index (%d rank(s))" % (n, d, args.storage, world))
+    main_run = Runner(env, n, d, k, nq, args.storage, args.seed, args.out)
+    log("timing %d steps" % args.steps)
+    elapsed, n_launch, scan_ms, bytes_per_launch = main_run.timed(args.steps, args.warmup)
+    stages = main_run.stages() if world > 1 else None
 
     # The metric has two halves (batch 1 and batch 1024).  `value` is the batch-1 half; the other
     # is measured right after it on the same resident corpus (not part of `value`).
     batch_leg = None
     if nq == 1 and not args.no_batch_leg:
-        nqb, steps_b = 1024, 5
-        qg = faiss.IndexFlatIP(d)
-        qg._b.add_synthetic(nqb, 4321, 0)
-        qb_dev = torch.from_numpy(qg.reconstruct_n(0, nqb)).to(dev)
-        del qg
+        log("batch-1024 leg")
+        rb = Runner(env, n, d, k, 1024, args.storage, args.seed, args.out, index=main_run.index)
+        batch_leg = rb.leg("batch1024", 5, 1, "the headline corpus, nq=1024")
+        del rb
 
-        def local_search_b(q, kk, D_loc, I_loc):
-            index._b.search_dev(nqb, q.data_ptr(), kk, D_loc.data_ptr(), I_loc.data_ptr(), base, st)
-
-        sb = ShardedFlatSearcher(local_search_b, 0, nqb, k, dev, stream=st)
-        hb = torch.empty_like(sb.out_packed, device="cpu").pin_memory()
-
-        def step_b():
-            sb.search(qb_dev)
-            hb.copy_(sb.out_packed, non_blocking=True)
-            stream.synchronize()
-
-        step_b()
-        index._b.profiling(True)
-        index._b.timing()
-        fence()
-        tb = time.perf_counter()
-        for _ in range(steps_b):
-            step_b()
-        fence()
-        el_b = time.perf_counter() - tb
-        index._b.profiling(False)
-        nl_b, ms_b, _ = index._b.timing()
-        if world > 1:
-            t = torch.tensor([el_b], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_b = float(t.item())
-        k_ms = ms_b / max(nl_b, 1)
-        peak_b = BF16_MFMA_PEAK_TF if args.storage == "bf16" else FP32_MFMA_PEAK_TF
-        ach_b = 2.0 * nqb * n_local * d / (k_ms * 1e-3) / 1e12
-        batch_leg = {"nq": nqb, "value": nqb * steps_b / el_b, "unit": "QPS", "steps": steps_b,
-                     "ms_per_step": el_b / steps_b * 1e3,
-                     "roofline": {"bound": "mfma", "achieved": ach_b, "peak": peak_b, "unit": "TFLOP/s",
-                                  "frac": ach_b / peak_b, "kernel": "flat_mfma_kernel", "avg_launch_ms": k_ms}}
-
+    out = None
     if rank == 0:
-        # outside the timed region: the last step's result must be a plausible top-k
-        Dn, In = D_host.numpy(), I_host.numpy()
-        assert ((In >= 0) & (In < n)).all(), "ids out of range"
-        assert (Dn[:, :-1] >= Dn[:, 1:]).all(), "scores not sorted best-first"
+        Dn, In = main_run.check_plausible()     # outside the timed region: a plausible top-k
         if args.dump_result:
             np.savez(args.dump_result, D=Dn, I=In)
         ms_per_step = elapsed / args.steps * 1e3
         qps = nq * args.steps / elapsed
-        avg_scan_ms = scan_ms / max(n_launch, 1)
-        launches_per_step = n_launch / float(args.steps)
-        flops = 2.0 * nq * n_local * d * (1.0 / launches_per_step if launches_per_step else 1.0)
-        bf = args.storage == "bf16"
-        mfma_peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
-        esz = 2 if bf else 4
-        # arithmetic intensity 2*nq/esz flop per byte against the ridge peak_flops / peak_bytes
-        hbm_bound = 2.0 * nq / esz <= mfma_peak * 1e3 / HBM_PEAK_GBS
-        if hbm_bound:
-            ach = bytes_per_launch / (avg_scan_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None}
-        else:
-            ach = flops / (avg_scan_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",
-                    "frac": ach / mfma_peak, "traffic": None}
-        # which kernel made the timed pass (the engine's dispatch, csrc/flat.hip search_device; the
-        # rocprofv3 summaries under profiles/ show the same names)
-        if k > 128:
-            kname = "flat_scan_kernel" if nq < (2 if bf else 3) else "flat_scan_kernel (pairs)"
-        elif nq <= 8 or (nq <= 16 and n_local < (1 << 19)):
-            kname = "flat_stream_kernel"
-        elif nq <= 192 and n_local >= (1 << 19):
-            kname = "flat_wide_kernel (sample + filter passes%s)" % ("" if nq <= 64 else ", %d query chunks" % ((nq + 63) // 64))
-        else:
-            kname = "flat_mfma_kernel"
-        roof.update({"kernel": kname, "avg_launch_ms": avg_scan_ms, "launches": n_launch,
-                     "algorithmic_bytes_per_launch": bytes_per_launch})
+        roof = roofline(nq, k, main_run.n_local, d, bf, n_launch, scan_ms, bytes_per_launch, args.steps)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1:
             try:
                 tj = json.load(open(tpath))
                 if (tj.get("rows") == n and tj.get("dim") == d and tj.get("nq") == nq
                         and tj.get("storage", "f32") == args.storage):
+                    # not measured in this run: the PMC counters need rocprofv3 around the process
                     roof["traffic"] = tj["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = tj.get("source")
+                    roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc pass of this command, "
+                                              "recorded earlier): " + str(tj.get("source")))
             except Exception:
                 pass
         out = {
@@ -278,19 +330,100 @@ def main():
             "config": {"workload": "%d x %d %s L2-normalised synthetic rows (seed %d), IndexFlatIP top-%d, nq=%d"
                                    % (n, d, "bf16" if bf else "fp32", args.seed, k, nq),
                        "rows": n, "dim": d, "k": k, "nq": nq, "storage": args.storage,
+                       "result": ("written to pinned host memory by the last kernel" if args.out == "pinned"
+                                  else "HBM + one D2H copy") + ", one stream synchronise per step",
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-gather + merge" % world
                                       if world > 1 else "1 GPU"},
             "roofline": roof,
         }
+        if stages is not None:
+            out["stages"] = {"per_rank": stages,
+                             "note": "ms per step on each rank's stream; allgather_ms includes waiting for the slowest rank"}
         if batch_leg is not None:
             out["batch1024"] = batch_leg
+
+    # ---- N > 1: BASELINE config 4 (north_star's scaling workload), rows split over the ranks
+    if world > 1 and not args.no_legs:
+        del main_run
+        torch.cuda.empty_cache()
+        rows_c4 = args.c4_rows
+        per_gb = rows_c4 * 768 * 4 / world / 1e9
+        if per_gb <= 250.0:
+            log("c4 leg: %d x 768 fp32 over %d ranks (%.1f GB per rank)" % (rows_c4, world, per_gb))
+            r4 = Runner(env, rows_c4, 768, 10, 1, "f32", args.seed, args.out)
+            leg = r4.leg("c4", 20, 3, "%d x 768 fp32 rows split over %d ranks, IndexFlatIP top-10, nq=1" % (rows_c4, world))
+            leg["stages"] = {"per_rank": r4.stages(10)}
+            leg["scaling"] = "strong"
+            if out is not None:
+                out["c4"] = leg
+            del r4
+        elif out is not None:
+            out["c4"] = {"skipped": "%.0f GB per rank does not fit" % per_gb}
+
+    # ---- N = 1: the other BASELINE configs, time-bounded, beside the headline
+    if world == 1 and not args.no_legs and nq == 1 and not bf:
+        legs = [x for x in args.legs.split(",") if x]
+        del main_run
+        torch.cuda.empty_cache()
+        if "c2" in legs:
+            log("c2 leg: 1M x 384 fp32")
+            r = Runner(env, 1_000_000, 384, 10, 1, "f32", args.seed, args.out)
+            out["c2"] = {"nq1": r.leg("c2", 300, 20, "1M x 384 fp32, IndexFlatIP top-10, nq=1")}
+            del r
+            r = Runner(env, 1_000_000, 384, 10, 64, "f32", args.seed, args.out)
+            out["c2"]["nq64"] = r.leg("c2", 100, 10, "1M x 384 fp32, IndexFlatIP top-10, nq=64")
+            del r
+        if "c3" in legs:
+            log("c3 leg: 10M x 768 bf16, nq=1024, k=100")
+            r = Runner(env, 10_000_000, 768, 100, 1024, "bf16", args.seed, args.out)
+            out["c3"] = r.leg("c3", 8, 2, "10M x 768 bf16 rows, IndexFlatIP top-100, nq=1024")
+            del r
+        if "c4_shard" in legs:
+            log("c4_shard leg: one rank's 12.5M x 768 fp32 shard of config 4 at 8 GPUs")
+            r = Runner(env, 12_500_000, 768, 10, 1, "f32", args.seed, args.out)
+            out["c4_shard"] = r.leg("c4_shard", 30, 5, "12.5M x 768 fp32 = one of 8 shards of 100M x 768, top-10, nq=1")
+            del r
+        torch.cuda.empty_cache()
+        if "c5" in legs:
+            try:
+                out["c5"] = c5_leg()
+            except Exception as e:   # the headline line must still be printed
+                out["c5"] = {"error": repr(e)}
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not bf:
-            out["cpu_baseline"] = cpu_baseline(args, Q)
+            log("cpu baseline")
+            from rag_system_amd import faiss_compat as faiss
+            qg = faiss.IndexFlatIP(d)
+            qg._b.add_synthetic(max(nq, 1), 4321, 0)
+            out["cpu_baseline"] = cpu_baseline(args, qg.reconstruct_n(0, max(nq, 1)))
         print(json.dumps(out), flush=True)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def c5_leg(n_queries=40):
+    """BASELINE config 5: strategy=rrf + MMR over 1M synthetic documents, whole query through the
+    host classes (benchmarks/hybrid_workload.py); parity-checked after the timed loop."""
+    from benchmarks.hybrid_workload import HybridWorkload, STAGES
+    wl = HybridWorkload(1_000_000, 200_000, 384, n_queries, 10, log)
+    for qi in range(3):
+        wl.query(qi)
+    tsum = {s: 0.0 for s in STAGES}
+    sb = {"bm25": 0.0, "tfidf": 0.0}
+    results = [wl.query(qi, tsum, sb) for qi in range(n_queries)]
+    checked = wl.check([0, 1, 2], results[:3])
+    nq = float(n_queries)
+    return {"workload": "strategy=rrf + MMR, 1M docs, vocab 200k, %d postings, dense 1M x 384 fp32, top_k=10" % wl.nnz,
+            "value": nq / tsum["total"], "unit": "QPS", "ms_per_query": tsum["total"] / nq * 1e3,
+            "stage_ms": {s: tsum[s] / nq * 1e3 for s in STAGES},
+            "sparse_roofline": {s: {"bound": "hbm", "achieved": sb[s] / tsum[s] / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": sb[s] / tsum[s] / 1e9 / HBM_PEAK_GBS,
+                                    "note": "algorithmic bytes / wall clock of the whole C-ABI call"}
+                                for s in ("bm25", "tfidf")},
+            "parity_checked_queries": checked}
 
 
 if __name__ == "__main__":

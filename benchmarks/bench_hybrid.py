@@ -39,31 +39,7 @@ def log(msg):
     print("[bench_hybrid %6.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
 
 
-def make_corpus(n_docs, vocab, seed):
-    rng = np.random.default_rng(seed)
-    sigma = 0.4
-    lens = np.clip(rng.lognormal(np.log(120.0) - 0.5 * sigma * sigma, sigma, n_docs), 8, 1000).astype(np.int64)
-    indptr = np.concatenate([np.zeros(1, np.int64), np.cumsum(lens)])
-    w = np.arange(1, vocab + 1, dtype=np.float64) ** -1.1
-    cdf = np.cumsum(w / w.sum())
-    terms = np.empty(int(indptr[-1]), dtype=np.int32)
-    step = 16_000_000
-    for lo in range(0, len(terms), step):           # chunked: bounded temporaries
-        hi = min(len(terms), lo + step)
-        terms[lo:hi] = np.searchsorted(cdf, rng.random(hi - lo)).astype(np.int32)
-    np.minimum(terms, vocab - 1, out=terms)
-    nq_terms = rng.integers(3, 9, size=4096)
-    return indptr, terms, cdf, nq_terms, rng
-
-
-def tfidf_matrix(n_docs, n_terms, indptr, rows, tf):
-    """TfidfVectorizer defaults on integer tokens: idf = ln((1+n)/(1+df)) + 1, l2 rows."""
-    from scipy.sparse import csc_matrix
-    from sklearn.preprocessing import normalize
-    df = np.diff(indptr)
-    idf = np.log((1.0 + n_docs) / (1.0 + df)) + 1.0
-    m = csc_matrix((tf * np.repeat(idf, df), rows, indptr), shape=(n_docs, n_terms)).tocsr()
-    return normalize(m, copy=False), idf
+from benchmarks.hybrid_workload import HybridWorkload, STAGES  # noqa: E402
 
 
 def main():
@@ -80,91 +56,17 @@ def main():
     args = ap.parse_args()
     n, V, d, top_k = args.docs, args.vocab, args.dim, args.top_k
 
-    from rag_system_amd import _lib, faiss_compat as faiss
-    from rag_system_amd.bm25 import BM25Okapi
-    from rag_system_amd.candidates import mmr_select, reciprocal_rank_fusion
-    from rag_system_amd.tfidf import TfidfScorer
+    from rag_system_amd import _lib
     _lib.engine(0)
-
-    log("generating %d documents over a %d-term vocabulary" % (n, V))
-    indptr, terms, cdf, nq_terms, rng = make_corpus(n, V, 777)
-    log("%d tokens; building BM25 postings (k1=1.0, b=0.65: config.py:37-38)" % len(terms))
-    bm = BM25Okapi.from_term_ids(indptr, terms, k1=1.0, b=0.65, keep_postings=True)
-    p_indptr, p_rows, p_tf = bm.postings
-    n_terms = len(p_indptr) - 1
-    nnz = len(p_rows)
-    log("%d distinct terms, %d postings; building TF-IDF matrix" % (n_terms, nnz))
-    M, tfidf_idf = tfidf_matrix(n, n_terms, p_indptr, p_rows, p_tf)
-    ts = TfidfScorer(None, M)
-    Mc = M.tocsc()
-    Mc.sort_indices()
-    log("dense index %d x %d" % (n, d))
-    index = faiss.IndexFlatIP(d)
-    index._b.add_synthetic(n, 1234, 0)
-    qgen = faiss.IndexFlatIP(d)
-    qgen._b.add_synthetic(args.queries, 4321, 0)
-    Qd = qgen.reconstruct_n(0, args.queries)
-    del qgen
-
-    queries = []                                 # raw integer tokens, as a tokenizer would hand them over
-    for qi in range(args.queries):
-        raw = np.minimum(np.searchsorted(cdf, rng.random(int(nq_terms[qi]))), V - 1)
-        queries.append([int(t) for t in raw])
-    vocab_map = bm._vocab                        # raw integer token -> term id
-
-    stages = ["dense", "bm25", "tfidf", "rrf", "mmr", "total"]
+    wl = HybridWorkload(n, V, d, args.queries, top_k, log)
+    n_terms, nnz = wl.n_terms, wl.nnz
+    stages = STAGES
     tsum = {s: 0.0 for s in stages}
     sparse_bytes = {"bm25": 0.0, "tfidf": 0.0}
     results = []
-    df_all = np.diff(p_indptr)
-
-    def one_query(qi, record):
-        raw = queries[qi]
-        tids = np.asarray([vocab_map[t] for t in raw if t in vocab_map], dtype=np.int64)
-        t0 = time.perf_counter()
-        D, I = index.search(Qd[qi:qi + 1], 9 * top_k)             # search_faiss(document mode, 3*top_k)
-        dense_rank = list(dict.fromkeys(int(i) for i in I[0]))[:3 * top_k]
-        t1 = time.perf_counter()
-        bI, bD = bm.top_k(raw, 3 * top_k)                         # search_bm25(3*top_k)
-        bm_rank = [int(i) for i in bI]
-        t2 = time.perf_counter()
-        fused = reciprocal_rank_fusion([dense_rank, bm_rank], k=60)
-        t3 = time.perf_counter()
-        # TF-IDF: every document is ranked (search_engine.py:332-336); only the candidates and
-        # the head of the ranking can reach the fused top_k (rag_system_amd/search_engine.py:245)
-        uq, cnt = np.unique(tids, return_counts=True)
-        cand = list(fused)
-        tI, tD, ranks = ts.ranks_from_row(uq, cnt * tfidf_idf[uq], top_k + len(cand), np.asarray(cand, dtype=np.int64))
-        t4 = time.perf_counter()
-        for doc, rk in zip(cand, ranks):
-            fused[doc] = fused[doc] + 1.0 / (60 + int(rk))
-        for rank, doc in enumerate(int(i) for i in tI):
-            if doc not in fused:
-                fused[doc] = 0 + 1.0 / (60 + rank)
-        order = sorted(fused.items(), key=lambda kv: kv[1], reverse=True)[:top_k]
-        t5 = time.perf_counter()
-        ids = [doc for doc, _ in order]
-        sel = mmr_select(Xh[ids], Qd[qi], [120] * len(ids), 0.5, top_k, None)   # search_engine.py:131-133
-        t6 = time.perf_counter()
-        if record:
-            tsum["dense"] += t1 - t0
-            tsum["bm25"] += t2 - t1
-            tsum["tfidf"] += t4 - t3
-            tsum["rrf"] += (t3 - t2) + (t5 - t4)
-            tsum["mmr"] += t6 - t5
-            tsum["total"] += t6 - t0
-            # postings: row 4 + val 8 + (bm25: doc_len 4) + score read+write 16; plus clearing and
-            # reading the n-row score vector (memset + top-k), plus one more read for the ranks
-            sparse_bytes["bm25"] += 32.0 * float(df_all[tids].sum()) + 16.0 * n
-            sparse_bytes["tfidf"] += 28.0 * float(df_all[uq].sum()) + 24.0 * n
-        return dict(dense=dense_rank, bm25=(bm_rank, bD), tfidf=([int(i) for i in tI], tD), cand=cand,
-                    ranks=[int(r) for r in ranks], fused=order, mmr=[ids[i] for i in sel], tids=tids)
-
-    log("copying the dense rows to the host once (MMR candidate embeddings)")
-    Xh = index.reconstruct_n(0, n)
     log("warm-up")
     for qi in range(min(3, args.queries)):
-        one_query(qi, False)
+        wl.query(qi)
     log("timing %d queries" % args.queries)
     prof = None
     if args.profile_loop:
@@ -172,7 +74,7 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     for qi in range(args.queries):
-        results.append(one_query(qi, True))
+        results.append(wl.query(qi, tsum, sparse_bytes))
     if prof is not None:
         import io
         import pstats
@@ -186,38 +88,8 @@ def main():
     # ---- parity at full size against the numpy restatement (oracle/)
     ncheck = min(8, args.queries)
     log("parity check against oracle/ on %d queries" % ncheck)
-    from oracle import dense as od
-    from oracle import fusion as ofu
-    from oracle import sparse as osp
-    all_ids = np.arange(n)
-    Dr, Ir, D64 = od.flat_search_synth(1234, 0, n, d, Qd[:ncheck], 9 * top_k)
-    for qi in range(ncheck):
-        r, tids = results[qi], results[qi]["tids"]
-        s_ref = osp.bm25_scores_postings(p_indptr, p_rows, p_tf, bm._idf_arr, np.asarray(bm.doc_len), bm.avgdl,
-                                         1.0, 0.65, tids)
-        top = np.lexsort((all_ids, -s_ref))[:3 * top_k]
-        assert top.tolist() == r["bm25"][0], "BM25 ids differ from the restatement (query %d)" % qi
-        assert s_ref[top].tobytes() == np.asarray(r["bm25"][1]).tobytes(), "BM25 scores differ bitwise"
-        uq, cnt = np.unique(tids, return_counts=True)
-        w = cnt * tfidf_idf[uq]
-        w = w / np.sqrt((w * w).sum())
-        t_ref = osp.tfidf_scores_postings(Mc.indptr, Mc.indices, Mc.data, uq, w, n)
-        t_order = np.lexsort((all_ids, -t_ref))
-        assert t_order[:len(r["tfidf"][0])].tolist() == r["tfidf"][0], "TF-IDF ids differ (query %d)" % qi
-        assert np.allclose(t_ref[t_order[:len(r["tfidf"][0])]], r["tfidf"][1], rtol=1e-12, atol=0), "TF-IDF scores differ"
-        full_rank = np.empty(n, dtype=np.int64)
-        full_rank[t_order] = all_ids
-        assert full_rank[r["cand"]].tolist() == r["ranks"], "TF-IDF ranks differ (query %d)" % qi
-        assert list(dict.fromkeys(int(i) for i in Ir[qi]))[:3 * top_k] == r["dense"], "dense ids differ (query %d)" % qi
-        # the reference's RRF: every entry of the three FULL rankings (search_engine.py:352-359)
-        fused = ofu.reciprocal_rank_fusion([[(i, 0.0) for i in r["dense"]], [(i, 0.0) for i in r["bm25"][0]],
-                                            [(int(i), 0.0) for i in t_order]], k=60)
-        order = sorted(fused.items(), key=lambda kv: kv[1], reverse=True)[:top_k]
-        assert order == r["fused"], "fused top_k differs from RRF over the full rankings (query %d)" % qi
-        ids = [a for a, _ in order]
-        sel = ofu.mmr_selection(Xh[ids], Qd[qi], [120] * len(ids), 0.5, top_k, None)
-        assert [ids[i] for i in sel] == r["mmr"], "MMR order differs (query %d)" % qi
-    checked = ncheck
+    checked = wl.check(list(range(ncheck)), results[:ncheck])
+    indptr, terms, queries, bm, Qd = wl.indptr, wl.terms, wl.queries, wl.bm, wl.Qd
 
     out = {
         "metric": "QPS, strategy=rrf (dense + BM25Okapi + TF-IDF + RRF + MMR) over %d synthetic documents" % n,

@@ -1,0 +1,186 @@
+"""BASELINE config 5 (strategy=rrf on synthetic documents) as a reusable workload: corpus and index
+construction, the per-query pipeline through the engine, and the full-size parity check against
+oracle/.  Used by benchmarks/bench_hybrid.py, bench.py's `c5` leg and tests/test_hybrid_full_gpu.py.
+
+Synthetic corpus: seed 777, vocabulary V, Zipf(1.1) term draws, document length
+lognormal with mean 120 tokens, one chunk per document; queries of 3-8 terms from the same Zipf;
+dense rows from the engine's generator (seed 1234), queries seed 4321.
+Per query (search_engine.py:320-350 with top_k = 10):
+    dense   index.search(q, 9*top_k)  -> first 3*top_k distinct documents     (rag_flat_search)
+    bm25    top 3*top_k chunks                                                 (rag_bm25_scores)
+    tfidf   scores of all documents; top (top_k + |A|) + ranks of A            (rag_tfidf_query)
+    rrf     1/(60+rank) over the three rankings                                (rag_rrf)
+    mmr     top_k of the fused top 3*top_k, stored vectors as embeddings       (rag_mmr)
+
+oracle/ is imported only inside check(): as the CHECKER of recorded results, never in anything timed.
+"""
+import time
+
+import numpy as np
+
+
+def make_corpus(n_docs, vocab, seed):
+    rng = np.random.default_rng(seed)
+    sigma = 0.4
+    lens = np.clip(rng.lognormal(np.log(120.0) - 0.5 * sigma * sigma, sigma, n_docs), 8, 1000).astype(np.int64)
+    indptr = np.concatenate([np.zeros(1, np.int64), np.cumsum(lens)])
+    w = np.arange(1, vocab + 1, dtype=np.float64) ** -1.1
+    cdf = np.cumsum(w / w.sum())
+    terms = np.empty(int(indptr[-1]), dtype=np.int32)
+    step = 16_000_000
+    for lo in range(0, len(terms), step):           # chunked: bounded temporaries
+        hi = min(len(terms), lo + step)
+        terms[lo:hi] = np.searchsorted(cdf, rng.random(hi - lo)).astype(np.int32)
+    np.minimum(terms, vocab - 1, out=terms)
+    nq_terms = rng.integers(3, 9, size=4096)
+    return indptr, terms, cdf, nq_terms, rng
+
+
+def tfidf_matrix(n_docs, n_terms, indptr, rows, tf):
+    """TfidfVectorizer defaults on integer tokens: idf = ln((1+n)/(1+df)) + 1, l2 rows."""
+    from scipy.sparse import csc_matrix
+    from sklearn.preprocessing import normalize
+    df = np.diff(indptr)
+    idf = np.log((1.0 + n_docs) / (1.0 + df)) + 1.0
+    m = csc_matrix((tf * np.repeat(idf, df), rows, indptr), shape=(n_docs, n_terms)).tocsr()
+    return normalize(m, copy=False), idf
+
+
+STAGES = ["dense", "bm25", "tfidf", "rrf", "mmr", "total"]
+
+
+class HybridWorkload:
+    def __init__(self, n_docs=1_000_000, vocab=200_000, dim=384, n_queries=50, top_k=10, log=None):
+        from rag_system_amd import faiss_compat as faiss
+        from rag_system_amd.bm25 import BM25Okapi
+        from rag_system_amd.tfidf import TfidfScorer
+        log = log or (lambda m: None)
+        self.n, self.V, self.d, self.top_k = n_docs, vocab, dim, top_k
+        log("generating %d documents over a %d-term vocabulary" % (n_docs, vocab))
+        self.indptr, self.terms, cdf, nq_terms, rng = make_corpus(n_docs, vocab, 777)
+        log("%d tokens; building BM25 postings (k1=1.0, b=0.65: config.py:37-38)" % len(self.terms))
+        self.bm = BM25Okapi.from_term_ids(self.indptr, self.terms, k1=1.0, b=0.65, keep_postings=True)
+        self.p_indptr, self.p_rows, self.p_tf = self.bm.postings
+        self.n_terms = len(self.p_indptr) - 1
+        self.nnz = len(self.p_rows)
+        log("%d distinct terms, %d postings; building TF-IDF matrix" % (self.n_terms, self.nnz))
+        self.M, self.tfidf_idf = tfidf_matrix(n_docs, self.n_terms, self.p_indptr, self.p_rows, self.p_tf)
+        self.ts = TfidfScorer(None, self.M)
+        log("dense index %d x %d" % (n_docs, dim))
+        self.index = faiss.IndexFlatIP(dim)
+        self.index._b.add_synthetic(n_docs, 1234, 0)
+        qgen = faiss.IndexFlatIP(dim)
+        qgen._b.add_synthetic(n_queries, 4321, 0)
+        self.Qd = qgen.reconstruct_n(0, n_queries)
+        del qgen
+        self.queries = []                            # raw integer tokens, as a tokenizer would hand them over
+        for qi in range(n_queries):
+            raw = np.minimum(np.searchsorted(cdf, rng.random(int(nq_terms[qi]))), vocab - 1)
+            self.queries.append([int(t) for t in raw])
+        self.vocab_map = self.bm._vocab              # raw integer token -> term id
+        self.df_all = np.diff(self.p_indptr)
+        self._Mc = None
+
+    def embeddings(self, ids):
+        """Stored dense rows of the given documents (MMR candidate embeddings)."""
+        ids = np.asarray(ids, dtype=np.int64)
+        out = np.empty((len(ids), self.d), dtype=np.float32)
+        for j, i in enumerate(ids):                  # top_k rows: a handful of small copies
+            out[j] = self.index.reconstruct_n(int(i), 1)[0]
+        return out
+
+    def query(self, qi, tsum=None, sparse_bytes=None):
+        """One strategy=rrf query through the engine; per-stage wall clock accumulated into tsum."""
+        from rag_system_amd.candidates import mmr_select, reciprocal_rank_fusion
+        top_k, n = self.top_k, self.n
+        raw = self.queries[qi]
+        tids = np.asarray([self.vocab_map[t] for t in raw if t in self.vocab_map], dtype=np.int64)
+        t0 = time.perf_counter()
+        D, I = self.index.search(self.Qd[qi:qi + 1], 9 * top_k)          # search_faiss(document mode, 3*top_k)
+        dense_rank = list(dict.fromkeys(int(i) for i in I[0]))[:3 * top_k]
+        t1 = time.perf_counter()
+        bI, bD = self.bm.top_k(raw, 3 * top_k)                           # search_bm25(3*top_k)
+        bm_rank = [int(i) for i in bI]
+        t2 = time.perf_counter()
+        fused = reciprocal_rank_fusion([dense_rank, bm_rank], k=60)
+        t3 = time.perf_counter()
+        # TF-IDF: every document is ranked (search_engine.py:332-336); only the candidates and
+        # the head of the ranking can reach the fused top_k (rag_system_amd/search_engine.py)
+        uq, cnt = np.unique(tids, return_counts=True)
+        cand = list(fused)
+        tI, tD, ranks = self.ts.ranks_from_row(uq, cnt * self.tfidf_idf[uq], top_k + len(cand),
+                                               np.asarray(cand, dtype=np.int64))
+        t4 = time.perf_counter()
+        for doc, rk in zip(cand, ranks):
+            fused[doc] = fused[doc] + 1.0 / (60 + int(rk))
+        for rank, doc in enumerate(int(i) for i in tI):
+            if doc not in fused:
+                fused[doc] = 0 + 1.0 / (60 + rank)
+        order = sorted(fused.items(), key=lambda kv: kv[1], reverse=True)[:top_k]
+        t5 = time.perf_counter()
+        ids = [doc for doc, _ in order]
+        emb = self.embeddings(ids)
+        t5b = time.perf_counter()                                        # fetching stored rows is not MMR time
+        sel = mmr_select(emb, self.Qd[qi], [120] * len(ids), 0.5, top_k, None)   # search_engine.py:131-133
+        t6 = time.perf_counter()
+        if tsum is not None:
+            tsum["dense"] += t1 - t0
+            tsum["bm25"] += t2 - t1
+            tsum["tfidf"] += t4 - t3
+            tsum["rrf"] += (t3 - t2) + (t5 - t4)
+            tsum["mmr"] += t6 - t5b
+            tsum["total"] += (t6 - t0) - (t5b - t5)
+        if sparse_bytes is not None:
+            # postings: row 4 + val 8 + (bm25: doc_len 4) + score read+write 16; plus clearing and
+            # reading the n-row score vector (memset + top-k), plus one more read for the ranks
+            sparse_bytes["bm25"] += 32.0 * float(self.df_all[tids].sum()) + 16.0 * n
+            sparse_bytes["tfidf"] += 28.0 * float(self.df_all[uq].sum()) + 24.0 * n
+        return dict(dense=dense_rank, bm25=(bm_rank, bD), tfidf=([int(i) for i in tI], tD), cand=cand,
+                    ranks=[int(r) for r in ranks], fused=order, mmr=[ids[i] for i in sel], tids=tids, emb=emb)
+
+    def check(self, qis, results):
+        """Full-size parity of recorded results against oracle/ (CHECKER role only): BM25 ids and
+        float64 scores bit-exact, TF-IDF ids exact and scores to 1e-12, ranks exact, dense ids exact,
+        fused top_k identical to RRF over the three FULL rankings (search_engine.py:352-359), MMR
+        order identical."""
+        from oracle import dense as od
+        from oracle import fusion as ofu
+        from oracle import sparse as osp
+        n, d, top_k = self.n, self.d, self.top_k
+        if self._Mc is None:
+            self._Mc = self.M.tocsc()
+            self._Mc.sort_indices()
+        Mc = self._Mc
+        all_ids = np.arange(n)
+        Qs = np.ascontiguousarray(self.Qd[list(qis)])
+        _Dr, Ir, _D64 = od.flat_search_synth(1234, 0, n, d, Qs, 9 * top_k)
+        for j, (qi, r) in enumerate(zip(qis, results)):
+            tids = r["tids"]
+            s_ref = osp.bm25_scores_postings(self.p_indptr, self.p_rows, self.p_tf, self.bm._idf_arr,
+                                             np.asarray(self.bm.doc_len), self.bm.avgdl, 1.0, 0.65, tids)
+            top = np.lexsort((all_ids, -s_ref))[:3 * top_k]
+            assert top.tolist() == r["bm25"][0], "BM25 ids differ from the restatement (query %d)" % qi
+            assert s_ref[top].tobytes() == np.asarray(r["bm25"][1]).tobytes(), "BM25 scores differ bitwise"
+            uq, cnt = np.unique(tids, return_counts=True)
+            w = cnt * self.tfidf_idf[uq]
+            w = w / np.sqrt((w * w).sum())
+            t_ref = osp.tfidf_scores_postings(Mc.indptr, Mc.indices, Mc.data, uq, w, n)
+            t_order = np.lexsort((all_ids, -t_ref))
+            assert t_order[:len(r["tfidf"][0])].tolist() == r["tfidf"][0], "TF-IDF ids differ (query %d)" % qi
+            assert np.allclose(t_ref[t_order[:len(r["tfidf"][0])]], r["tfidf"][1], rtol=1e-12, atol=0), \
+                "TF-IDF scores differ"
+            full_rank = np.empty(n, dtype=np.int64)
+            full_rank[t_order] = all_ids
+            assert full_rank[r["cand"]].tolist() == r["ranks"], "TF-IDF ranks differ (query %d)" % qi
+            assert list(dict.fromkeys(int(i) for i in Ir[j]))[:3 * top_k] == r["dense"], \
+                "dense ids differ (query %d)" % qi
+            fused = ofu.reciprocal_rank_fusion([[(i, 0.0) for i in r["dense"]], [(i, 0.0) for i in r["bm25"][0]],
+                                                [(int(i), 0.0) for i in t_order]], k=60)
+            order = sorted(fused.items(), key=lambda kv: kv[1], reverse=True)[:top_k]
+            assert order == r["fused"], "fused top_k differs from RRF over the full rankings (query %d)" % qi
+            ids = [a for a, _ in order]
+            emb = np.stack([od.synth_rows(1234, int(i), 1, d)[0] for i in ids])
+            assert emb.tobytes() == r["emb"].tobytes(), "stored rows differ from the generator (query %d)" % qi
+            sel = ofu.mmr_selection(emb, self.Qd[qi], [120] * len(ids), 0.5, top_k, None)
+            assert [ids[i] for i in sel] == r["mmr"], "MMR order differs (query %d)" % qi
+        return len(qis)

@@ -14,10 +14,18 @@
  *   - The caller owns every host buffer; the library owns device memory.
  *   - Pointers named *_dev are device pointers (HBM) on the device selected by
  *     rag_init(); everything else is host memory.
- *   - `stream` arguments are a hipStream_t passed as void* (NULL = the
- *     library's own stream).  *_dev entry points are asynchronous on `stream`.
+ *   - `stream` arguments are a hipStream_t passed as void*; NULL is HIP's null
+ *     stream, as in every HIP API (rag_lib_stream() returns the library's own
+ *     non-blocking stream, the one the host entry points run on).  *_dev entry
+ *     points are asynchronous on `stream` and ordered with the caller's other
+ *     work on that stream only.
  *   - One mutex per handle: add/search on one handle may be called from
  *     different host threads (the reference UI does, UI_manager.py:753,883).
+ *     A handle's search workspaces are shared by its searches: a search on a
+ *     different stream than the handle's previous one first waits (on the
+ *     device) for everything enqueued on that previous stream, which must
+ *     therefore still exist.  Searches on one handle never overlap on the GPU;
+ *     use one handle per stream for concurrency.
  *   - There is NO CPU fallback: without a usable GPU rag_init() fails with
  *     RAG_ERR_NO_DEVICE and every other call fails with RAG_ERR_NOT_INIT.
  */
@@ -65,8 +73,12 @@ int rag_init(int device_id);
 const char* rag_last_error(void);
 /* Number of HIP devices visible (0 if none / no driver). */
 int rag_device_count(void);
-/* ABI version of this header (bumped on incompatible change). */
+/* ABI version of this header (bumped on incompatible change; 2: a NULL stream is HIP's null
+ * stream, no longer the library's own). */
 int rag_abi_version(void);
+/* The library's own stream (hipStream_t, created non-blocking by rag_init): host entry points
+ * such as rag_flat_search run and synchronise on it.  No counterpart in the reference. */
+int rag_lib_stream(void** out);
 
 /* ---- dense flat index -------------------------------------------------- */
 

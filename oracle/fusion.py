@@ -27,12 +27,15 @@ def detect_knee(scores):
     return scores[max_drop_index + 1]
 
 
-def mmr_selection(cand_emb, query_vec, byte_lens, lambda_param=0.5, top_k=None, max_context_bytes=None):
-    """search_engine.py:419-465 with the model outputs given: returns selected indices."""
+def mmr_selection(cand_emb, query_vec, byte_lens, lambda_param=0.5, top_k=None, max_context_bytes=None,
+                  return_trace=False):
+    """search_engine.py:419-465 with the model outputs given: returns selected indices.
+    return_trace: also the list of argmax steps (n_selected_before, picked index, accepted) --
+    a pick the byte budget rejects (:457-463) is a step too."""
     from sklearn.metrics.pairwise import cosine_similarity
     n = len(cand_emb)
     if n == 0:
-        return []
+        return ([], []) if return_trace else []
     top_k = top_k if top_k is not None else n
     candidate_embeddings = np.array(cand_emb, dtype="float32")
     norms = np.linalg.norm(candidate_embeddings, axis=1, keepdims=True)
@@ -43,6 +46,7 @@ def mmr_selection(cand_emb, query_vec, byte_lens, lambda_param=0.5, top_k=None, 
     selected_indices = []
     candidate_indices = list(range(n))
     first_index = int(np.argmax(query_similarities))
+    trace = [(0, first_index, True)]
     selected_indices.append(first_index)
     candidate_indices.remove(first_index)
     total_bytes = byte_lens[first_index]
@@ -62,21 +66,25 @@ def mmr_selection(cand_emb, query_vec, byte_lens, lambda_param=0.5, top_k=None, 
         best_idx = candidate_indices[best_idx_relative]
         if max_context_bytes is not None:
             if total_bytes + byte_lens[best_idx] > max_context_bytes:
+                trace.append((len(selected_indices), best_idx, False))
                 candidate_indices.remove(best_idx)
                 continue
             else:
                 total_bytes += byte_lens[best_idx]
+        trace.append((len(selected_indices), best_idx, True))
         selected_indices.append(best_idx)
         candidate_indices.remove(best_idx)
-    return selected_indices
+    return (selected_indices, trace) if return_trace else selected_indices
 
 
-def mmr_margin(cand_emb, query_vec, lambda_param, selected):
-    """Smallest gap between the chosen candidate's MMR score and the runner-up over the
-    selection steps (float64): a selection that differs from the oracle's is only acceptable
-    where this gap is within float32 noise."""
+def mmr_trace_margins(cand_emb, query_vec, lambda_param, trace):
+    """float64 gap between the picked candidate's MMR score and the best other live candidate at
+    EVERY argmax step of `trace` (budget-rejected picks included), replaying the live / selected
+    sets the trace implies.  A selection that differs from the oracle's is only acceptable where
+    one of the steps leading to the first differing position has a gap within float32 noise."""
     E = np.asarray(cand_emb, dtype=np.float64)
-    E = E / np.maximum(np.linalg.norm(E, axis=1, keepdims=True), 1e-300)
+    nrm = np.linalg.norm(E, axis=1, keepdims=True)
+    E = E / np.where(nrm == 0, 1e-9, nrm)
     q = np.asarray(query_vec, dtype=np.float64)
     q = q / max(np.linalg.norm(q), 1e-300)
     simq = E @ q
@@ -84,13 +92,14 @@ def mmr_margin(cand_emb, query_vec, lambda_param, selected):
     live = list(range(len(E)))
     sel = []
     gaps = []
-    for step, pick in enumerate(selected):
-        if step == 0:
+    for _nsel, pick, accepted in trace:
+        if not sel:
             sc = {i: simq[i] for i in live}
         else:
             sc = {i: lambda_param * simq[i] - (1 - lambda_param) * max(G[i, j] for j in sel) for i in live}
         others = [v for i, v in sc.items() if i != pick]
         gaps.append(sc[pick] - max(others) if others else np.inf)
-        sel.append(pick)
+        if accepted:
+            sel.append(pick)
         live.remove(pick)
     return gaps

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rag_last_error": (C.c_char_p, []),
     "rag_device_count": (C.c_int, []),
     "rag_abi_version": (C.c_int, []),
+    "rag_lib_stream": (C.c_int, [C.POINTER(_p)]),
     "rag_flat_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
     "rag_flat_free": (None, [_p]),
     "rag_flat_reserve": (C.c_int, [_p, _i64]),
@@ -171,6 +172,14 @@ def engine(device=None):
         elif _inited_device != int(device):
             raise ValueError("engine already initialised on device %d" % _inited_device)
     return lib
+
+
+def lib_stream():
+    """hipStream_t (int) of the library's own stream: what the host entry points run on."""
+    lib = engine()
+    out = C.c_void_p()
+    check(lib.rag_lib_stream(C.byref(out)), lib)
+    return out.value or 0
 
 
 def ptr(a):

@@ -670,6 +670,11 @@ struct rag_flat {
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+    // stream of the last asynchronous search on this handle: the workspaces above are shared by every
+    // search, so a search on ANOTHER stream first waits for everything enqueued on this one
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t order_ev = nullptr;
     std::mutex mu;
 };
 
@@ -759,6 +764,9 @@ int flush_staged(rag_flat* h) {
     return RAG_OK;
 }
 
+// hipFree waits for all work on the device before it releases memory, so replacing a workspace is
+// safe even while an earlier asynchronous search (on any stream) still reads the old one; it costs
+// a device-wide wait, once per growth.
 template <typename T>
 int grow(T*& p, int64_t& cap, int64_t need) {
     if (need <= cap) return RAG_OK;
@@ -770,6 +778,44 @@ int grow(T*& p, int64_t& cap, int64_t need) {
     cap = want;
     return RAG_OK;
 }
+
+// Event pair around the dominant kernel of a search (rag_flat_profiling).  A pair that was taken
+// but never completed -- an early error return between begin() and end() -- goes back to the free
+// list instead of leaking.
+struct ProfPair {
+    rag_flat* h;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool done = false;
+    explicit ProfPair(rag_flat* hh) : h(hh) {}
+    int begin(hipStream_t st) {
+        if (!h->prof) return RAG_OK;
+        if (!h->ev_free.empty()) {
+            e0 = h->ev_free.back().first;
+            e1 = h->ev_free.back().second;
+            h->ev_free.pop_back();
+        } else {
+            RAG_HIP(hipEventCreate(&e0));
+            hipError_t e = hipEventCreate(&e1);
+            if (e != hipSuccess) {
+                (void)hipEventDestroy(e0);
+                e0 = nullptr;
+                return fail(RAG_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+            }
+        }
+        RAG_HIP(hipEventRecord(e0, st));
+        return RAG_OK;
+    }
+    int end(hipStream_t st) {
+        if (!e0) return RAG_OK;
+        RAG_HIP(hipEventRecord(e1, st));
+        h->ev_used.emplace_back(e0, e1);
+        done = true;
+        return RAG_OK;
+    }
+    ~ProfPair() {
+        if (e0 && !done) h->ev_free.emplace_back(e0, e1);
+    }
+};
 
 struct ScanCfg {
     int R, NQ, KS, metric;
@@ -847,6 +893,22 @@ int prepare_l2_norms(rag_flat* h, const float* qf, int64_t nq, hipStream_t st) {
     rc = grow(h->ws_qn, h->ws_qn_cap, nq);
     if (rc) return rc;
     return mfma_row_norms(qf, ld, false, 0, nq, h->ws_qn, st);
+}
+
+// The search workspaces (candidate lists, thresholds, padded queries, counters) are per handle,
+// and the mutex only covers the host side of an asynchronous call.  When a search arrives on a
+// different stream than the previous one, everything enqueued so far on the previous stream is
+// made a dependency of the new stream (event recorded there now, waited for here), so two searches
+// on one handle never overlap on the device.  Same stream: nothing to do (stream order).
+int order_after_previous(rag_flat* h, hipStream_t st) {
+    if (h->last_stream_valid && h->last_stream != st) {
+        if (!h->order_ev) RAG_HIP(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+        RAG_HIP(hipEventRecord(h->order_ev, h->last_stream));
+        RAG_HIP(hipStreamWaitEvent(st, h->order_ev, 0));
+    }
+    h->last_stream = st;
+    h->last_stream_valid = true;
+    return RAG_OK;
 }
 
 // The whole device-side search: q_dev (nq x d) -> D_dev/I_dev (nq x k) on `st`.
@@ -984,18 +1046,9 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             rc = grow(h->ws_cnt, h->ws_cnt_cap, 2 * nq + 1);
             if (rc) return rc;
         }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->prof) {
-            if (!h->ev_free.empty()) {
-                e0 = h->ev_free.back().first;
-                e1 = h->ev_free.back().second;
-                h->ev_free.pop_back();
-            } else {
-                RAG_HIP(hipEventCreate(&e0));
-                RAG_HIP(hipEventCreate(&e1));
-            }
-            RAG_HIP(hipEventRecord(e0, st));
-        }
+        ProfPair prof(h);
+        rc = prof.begin(st);
+        if (rc) return rc;
         if (!h->zero16) {
             RAG_HIP(hipMalloc(&h->zero16, 64));
             RAG_HIP(hipMemsetAsync(h->zero16, 0, 64, st));
@@ -1013,10 +1066,8 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                 rc = mfma_launch(plan, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
                                  h->ws_qn, h->zero16, st);
             if (rc) return rc;
-            if (h->prof) {
-                RAG_HIP(hipEventRecord(e1, st));
-                h->ev_used.emplace_back(e0, e1);
-            }
+            rc = prof.end(st);
+            if (rc) return rc;
             mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, stream ? sp.nlists : plan.nlists, k, D_dev,
                                                        I_dev, (long long)id_base, k, 0, nullptr);
             RAG_HIP(hipGetLastError());
@@ -1063,10 +1114,8 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             rc = mfma_launch(pf, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
                              h->ws_qn, h->zero16, st, nullptr, h->ws_thr, counts);
         if (rc) return rc;
-        if (h->prof) {
-            RAG_HIP(hipEventRecord(e1, st));
-            h->ev_used.emplace_back(e0, e1);
-        }
+        rc = prof.end(st);
+        if (rc) return rc;
         // 3. exact top-k of each append buffer
 #define RAG_SELECT(KSV)                                                                                             \
     do {                                                                                                            \
@@ -1109,25 +1158,14 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                 if (rc) return rc;
                 rc = grow(h->ws_id, h->ws_id_cap, (int64_t)cn * sp4.nlists * k);
                 if (rc) return rc;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (h->prof) {
-                    if (!h->ev_free.empty()) {
-                        e0 = h->ev_free.back().first;
-                        e1 = h->ev_free.back().second;
-                        h->ev_free.pop_back();
-                    } else {
-                        RAG_HIP(hipEventCreate(&e0));
-                        RAG_HIP(hipEventCreate(&e1));
-                    }
-                    RAG_HIP(hipEventRecord(e0, st));
-                }
+                ProfPair prof(h);
+                rc = prof.begin(st);
+                if (rc) return rc;
                 rc = stream_launch(sp4, h->x, (long long)n, dch, Qb + (size_t)q0 * qrow, cn, k, h->metric, h->ws_key,
                                    h->ws_id, h->xnorm, h->ws_qn ? h->ws_qn + q0 : nullptr, st);
                 if (rc) return rc;
-                if (h->prof) {
-                    RAG_HIP(hipEventRecord(e1, st));
-                    h->ev_used.emplace_back(e0, e1);
-                }
+                rc = prof.end(st);
+                if (rc) return rc;
                 mf4<<<(unsigned)cn, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, sp4.nlists, k, D_dev + q0 * k,
                                                             I_dev + q0 * k, (long long)id_base, k, 0, nullptr);
                 RAG_HIP(hipGetLastError());
@@ -1181,27 +1219,16 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             if (smem > 48 * 1024)
                 RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (h->prof) {
-                if (!h->ev_free.empty()) {
-                    e0 = h->ev_free.back().first;
-                    e1 = h->ev_free.back().second;
-                    h->ev_free.pop_back();
-                } else {
-                    RAG_HIP(hipEventCreate(&e0));
-                    RAG_HIP(hipEventCreate(&e1));
-                }
-                RAG_HIP(hipEventRecord(e0, st));
-            }
+            ProfPair prof(h);
+            rc = prof.begin(st);
+            if (rc) return rc;
             fn<<<(unsigned)nb, SCAN_THREADS, smem, st>>>(reinterpret_cast<const f32x4*>(h->x), (long long)n, dch,
                                                         reinterpret_cast<const f32x4*>(qf + q0 * ld), kp,
                                                         h->ws_key, h->ws_id, fl_k ? fl_k + q0 : nullptr,
                                                         fl_i ? fl_i + q0 : nullptr);
             RAG_HIP(hipGetLastError());
-            if (h->prof) {
-                RAG_HIP(hipEventRecord(e1, st));
-                h->ev_used.emplace_back(e0, e1);
-            }
+            rc = prof.end(st);
+            if (rc) return rc;
             merge_fn_t mf = pick_merge(KSp, h->metric);
             mf<<<(unsigned)NQ, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, (int)nb, kp, D_dev + q0 * k,
                                                        I_dev + q0 * k, (long long)id_base, k, done, nullptr);
@@ -1241,7 +1268,7 @@ void rag_flat_free(rag_flat_t* h) {
     if (!h) return;
     {
         std::lock_guard<std::mutex> lk(h->mu);
-        if (lib_stream()) (void)hipStreamSynchronize(lib_stream());
+        (void)hipDeviceSynchronize();  // searches may still be running on caller streams
         (void)hipFree(h->x);
         (void)hipFree(h->ws_q);
         (void)hipFree(h->ws_qb);
@@ -1261,6 +1288,7 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_D);
         (void)hipFree(h->ws_I);
         if (h->pin) (void)hipHostFree(h->pin);
+        if (h->order_ev) (void)hipEventDestroy(h->order_ev);
         for (auto& p : h->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto& p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     }
@@ -1305,7 +1333,7 @@ int rag_flat_add_dev(rag_flat_t* h, int64_t n, const float* x_dev, void* stream)
     if (rc) return rc;
     rc = ensure_capacity(h, h->ndev + n);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : lib_stream();
+    hipStream_t st = (hipStream_t)stream;  // NULL = HIP's null stream
     float* dst = reinterpret_cast<float*>(h->x) + (size_t)h->ndev * h->ld;
     if (h->dtype == RAG_DTYPE_BF16) {
         rc = convert_rows_dev(h, x_dev, h->ndev, n, st);
@@ -1370,8 +1398,10 @@ int rag_flat_search_dev(rag_flat_t* h, int64_t nq, const float* q_dev, int k, fl
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = flush_staged(h);
     if (rc) return rc;
-    return search_device(h, nq, q_dev, k, D_dev, reinterpret_cast<long long*>(I_dev), id_base,
-                         stream ? (hipStream_t)stream : lib_stream());
+    hipStream_t st = (hipStream_t)stream;  // NULL = HIP's null stream, as in any HIP API
+    rc = order_after_previous(h, st);
+    if (rc) return rc;
+    return search_device(h, nq, q_dev, k, D_dev, reinterpret_cast<long long*>(I_dev), id_base, st);
 }
 
 int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I) {
@@ -1384,6 +1414,8 @@ int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, 
     int rc = flush_staged(h);
     if (rc) return rc;
     hipStream_t st = lib_stream();
+    rc = order_after_previous(h, st);
+    if (rc) return rc;
     rc = grow(h->ws_hq, h->ws_hq_cap, nq * h->d);
     if (rc) return rc;
     if (nq * k > h->ws_out_cap) {
@@ -1473,7 +1505,7 @@ int rag_topk_merge_strided_dev(int metric, int nlists, int64_t nq, int k, const 
     if (stride_D < nq * k || stride_I < nq * k) return fail(RAG_ERR_INVALID_ARG, "list stride smaller than nq*k");
     if (metric != RAG_METRIC_IP && metric != RAG_METRIC_L2) return fail(RAG_ERR_INVALID_ARG, "bad metric");
     if (nq == 0) return RAG_OK;
-    hipStream_t st = stream ? (hipStream_t)stream : lib_stream();
+    hipStream_t st = (hipStream_t)stream;  // NULL = HIP's null stream
     const int KS = ks_for(k);
     const long long* Ill = reinterpret_cast<const long long*>(Il);
     long long* Io = reinterpret_cast<long long*>(I);

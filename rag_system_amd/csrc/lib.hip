@@ -42,7 +42,7 @@ Options& options() { return g_opt; }
 
 extern "C" {
 
-int rag_abi_version(void) { return 1; }
+int rag_abi_version(void) { return 2; }
 
 const char* rag_last_error(void) { return rag::g_err.c_str(); }
 
@@ -77,6 +77,13 @@ int rag_init(int device_id) {
     RAG_HIP(hipStreamCreateWithFlags(&rag::g_stream, hipStreamNonBlocking));
     rag::g_dev = device_id;
     rag::g_init = true;
+    return RAG_OK;
+}
+
+int rag_lib_stream(void** out) {
+    RAG_REQUIRE_INIT();
+    if (!out) return rag::fail(RAG_ERR_INVALID_ARG, "out is NULL");
+    *out = (void*)rag::g_stream;
     return RAG_OK;
 }
 

@@ -63,10 +63,12 @@ class _HipFlatBackend:
         _lib.check(self._lib.rag_flat_search(self._h, nq, _lib.ptr(q), int(k), _lib.ptr(D), _lib.ptr(I)), self._lib)
         return D, I
 
-    def search_dev(self, nq, q_dev, k, D_dev, I_dev, id_base=0, stream=None):
+    def search_dev(self, nq, q_dev, k, D_dev, I_dev, id_base=0, stream=0):
+        """Asynchronous on `stream` (a hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream;
+        0 = HIP's null stream = torch's default stream): ordered with the caller's other work there."""
         _lib.check(self._lib.rag_flat_search_dev(self._h, int(nq), C.c_void_p(q_dev), int(k), C.c_void_p(D_dev),
-                                                 C.c_void_p(I_dev), int(id_base),
-                                                 C.c_void_p(stream) if stream else None), self._lib)
+                                                 C.c_void_p(I_dev), int(id_base), C.c_void_p(int(stream or 0))),
+                   self._lib)
 
     def reset(self):
         _lib.check(self._lib.rag_flat_reset(self._h), self._lib)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "librag_mi355x.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes and include/rag_mi355x.h disagree"
-    assert lib.rag_abi_version() == 1
+    assert lib.rag_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -267,11 +267,12 @@ def test_sharded_search_and_device_merge(engine):
         torch.cuda.synchronize()
         assert np.array_equal(Im.cpu().numpy(), Iw) and np.array_equal(Dm.cpu().numpy(), Dw)
         # single-rank searcher writes through the packed views too
-        s1 = ShardedFlatSearcher(lambda q, kk, Dloc, Iloc: whole._b.search_dev(nq, q.data_ptr(), kk, Dloc.data_ptr(),
-                                                                              Iloc.data_ptr(), 0, st),
-                                 metric, nq, k, dev, stream=st)
+        side = torch.cuda.Stream(dev)
+        s1 = ShardedFlatSearcher(lambda q, kk, Dloc, Iloc, sh: whole._b.search_dev(nq, q.data_ptr(), kk, Dloc.data_ptr(),
+                                                                                  Iloc.data_ptr(), 0, sh),
+                                 metric, nq, k, dev, stream=side)
         D1, I1 = s1.search(qd)
-        torch.cuda.synchronize()
+        side.synchronize()      # the searcher's own stream, not the device
         assert np.array_equal(I1.cpu().numpy(), Iw) and np.array_equal(D1.cpu().numpy(), Dw)
 
 

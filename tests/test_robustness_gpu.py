@@ -133,3 +133,72 @@ def test_extreme_shapes(engine):
             X64, Q64 = X.astype(np.float64), Q.astype(np.float64)
             od.check_topk(D, I, D64, Ir, 1e-5, 2e-6,
                           lambda qi, ids: (X64[ids] @ Q64[qi]) if metric == 0 else ((X64[ids] - Q64[qi]) ** 2).sum(1))
+
+
+@pytest.mark.parametrize("which", ["default", "side"])
+def test_device_search_is_ordered_on_the_callers_stream(engine, which):
+    """rag_flat_search_dev is asynchronous on the stream it is given -- 0 is HIP's null stream, i.e.
+    torch's default stream -- so a copy enqueued behind it on the same stream sees its result with no
+    device-wide synchronisation.  A different query every step; the copy of step i is checked after
+    synchronising that stream only.  (A stale or racing result would show as another query's ids.)"""
+    import torch
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(71)
+    n, d, k, steps = 200_000, 128, 10, 24
+    X = _rand_unit(rng, n, d)
+    Q = _rand_unit(rng, steps, d)
+    idx = faiss.IndexFlatIP(d)
+    idx.add(X)
+    idx.search(Q[:1], k)                      # flush the staged rows
+    _, Ir, D64 = od.flat_search(X, Q, k, 0)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream() if which == "default" else torch.cuda.Stream(dev)
+    if which == "default":
+        assert stream.cuda_stream == 0
+    X64 = X.astype(np.float64)
+    with torch.cuda.stream(stream):
+        qd = torch.from_numpy(Q).to(dev)
+        Dd = torch.empty((1, k), dtype=torch.float32, device=dev)
+        Id = torch.empty((1, k), dtype=torch.int64, device=dev)
+        Dh = torch.empty((steps, k), dtype=torch.float32).pin_memory()
+        Ih = torch.empty((steps, k), dtype=torch.int64).pin_memory()
+        stream.synchronize()
+        for i in range(steps):
+            idx._b.search_dev(1, qd[i:i + 1].data_ptr(), k, Dd.data_ptr(), Id.data_ptr(), 0, stream.cuda_stream)
+            Dh[i:i + 1].copy_(Dd, non_blocking=True)
+            Ih[i:i + 1].copy_(Id, non_blocking=True)
+        stream.synchronize()                  # this stream only
+    od.check_topk(Dh.numpy(), Ih.numpy(), D64, Ir, 1e-5, 2e-6,
+                  lambda qi, ids: X64[ids] @ Q[qi].astype(np.float64))
+
+
+def test_two_streams_on_one_handle_do_not_overlap(engine):
+    """A handle's workspaces are shared by its searches: a search on another stream first waits for
+    the handle's previous stream (include/rag_mi355x.h).  Alternating streams, no host
+    synchronisation in between, different queries and k; every result must be its own query's."""
+    import torch
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(72)
+    n, d = 300_000, 64
+    X = _rand_unit(rng, n, d)
+    idx = faiss.IndexFlatIP(d)
+    idx.add(X)
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream()]
+    jobs = []
+    for i in range(18):
+        nq, k = [(1, 10), (5, 30), (20, 10), (3, 100)][i % 4]
+        Q = _rand_unit(rng, nq, d)
+        jobs.append((Q, k, torch.from_numpy(Q).to(dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+                     torch.empty((nq, k), dtype=torch.int64, device=dev)))
+    idx.search(jobs[0][0], 10)
+    torch.cuda.synchronize()
+    for i, (Q, k, qd, Dd, Id) in enumerate(jobs):
+        idx._b.search_dev(Q.shape[0], qd.data_ptr(), k, Dd.data_ptr(), Id.data_ptr(), 0,
+                          streams[i % 3].cuda_stream)
+    torch.cuda.synchronize()
+    X64 = X.astype(np.float64)
+    for Q, k, _qd, Dd, Id in jobs:
+        _, Ir, D64 = od.flat_search(X, Q, k, 0)
+        od.check_topk(Dd.cpu().numpy(), Id.cpu().numpy(), D64, Ir, 1e-5, 2e-6,
+                      lambda qi, ids: X64[ids] @ Q[qi].astype(np.float64))

@@ -159,8 +159,13 @@ def test_rrf_matches_reference_restatement(engine):
 
 
 def test_mmr_selection_matches_reference_restatement(engine):
+    """search_engine.py:396-468 incl. the max_context_bytes branch (:457-463: a pick the budget rejects
+    is dropped without being selected, and the loop goes on).  A selection that differs from the
+    oracle's must be justified the same way with and without a budget: one of the argmax steps that
+    lead to the first differing position (rejected picks included) is a float32 near-tie in float64."""
     from rag_system_amd.candidates import mmr_select
     rng = np.random.default_rng(51)
+    n_cases = n_div = n_reject_steps = n_budget_cut = 0
     for trial in range(12):
         C = int(rng.integers(1, 40))
         d = int(rng.choice([8, 384, 768]))
@@ -172,14 +177,51 @@ def test_mmr_selection_matches_reference_restatement(engine):
         q = rng.standard_normal(d).astype(np.float32)
         q /= np.linalg.norm(q)
         blen = rng.integers(10, 2000, C).astype(np.int64)
-        for lam, top_k, budget in [(0.5, None, None), (0.85, 5, None), (0.7, 10, 3000), (0.0, 4, None), (1.0, 6, 1500)]:
-            exp = ofu.mmr_selection(E, q, blen.tolist(), lam, top_k, budget)
+        for lam, top_k, budget in [(0.5, None, None), (0.85, 5, None), (0.7, 10, 3000), (0.0, 4, None), (1.0, 6, 1500),
+                                   (0.6, None, 2500), (0.85, 8, 0), (0.5, 12, 10 ** 9)]:
+            exp, trace = ofu.mmr_selection(E, q, blen.tolist(), lam, top_k, budget, return_trace=True)
             got = mmr_select(E, q, blen, lam, top_k, budget)
-            if got != exp:
-                # acceptable only as a float32 near-tie at the first step where they diverge
-                j = next(i for i, (a, b2) in enumerate(zip(got, exp)) if a != b2) if len(got) == len(exp) else 0
-                gaps = ofu.mmr_margin(E, q, lam, exp[:j + 1]) if budget is None else [0.0]
-                assert abs(gaps[-1]) < 1e-5, "MMR diverges from the oracle beyond float32 noise: %s vs %s" % (got, exp)
+            n_cases += 1
+            rejects = sum(1 for _n, _p, ok in trace if not ok)
+            n_reject_steps += rejects
+            n_budget_cut += 1 if rejects else 0
+            # invariants of the budget rule whatever the tie-breaking: first pick unchecked, then the sum stays in budget
+            assert len(set(got)) == len(got) and len(got) <= (top_k if top_k is not None else C)
+            if budget is not None and len(got) > 1:
+                assert int(blen[got].sum()) <= max(budget, int(blen[got[0]]))
+            if got == exp:
+                continue
+            n_div += 1
+            m = min(len(got), len(exp))
+            j = next((i for i in range(m) if got[i] != exp[i]), m)
+            gaps = ofu.mmr_trace_margins(E, q, lam, trace)
+            leading = [abs(g) for (nsel, _p, _ok), g in zip(trace, gaps) if nsel == j]
+            assert leading and min(leading) < 1e-5, (
+                "MMR diverges from the oracle beyond float32 noise at position %d: %s vs %s (lam=%s top_k=%s "
+                "budget=%s, float64 gaps of the steps leading there: %s)" % (j, got, exp, lam, top_k, budget, leading))
+    assert n_reject_steps >= 20 and n_budget_cut >= 8, "the byte-budget branch was not exercised"
+    assert n_div <= n_cases // 10, "%d of %d selections differ from the oracle" % (n_div, n_cases)
+
+
+def test_mmr_byte_budget_hand_case(engine):
+    """Hand-checkable budget case: orthogonal candidates (no diversity penalty differences), scores
+    descending by index, lambda = 1 -> picks go 0,1,2,... and the budget decides alone."""
+    from rag_system_amd.candidates import mmr_select
+    d = 8
+    q = np.zeros(d, np.float32)
+    q[0] = 1.0
+    E = np.zeros((6, d), np.float32)
+    for i in range(6):
+        E[i, 0] = 1.0 - 0.1 * i
+        E[i, i + 1] = 0.2 + 0.1 * i       # cos to q strictly decreasing with i
+    blen = np.array([500, 400, 300, 50, 700, 60], np.int64)
+    # first pick (0: 500 B) is never checked; 1 (400) fits 1000; 2 (300) does not -> dropped; 3 (50) fits; 4 no; 5 no (60 > 50 left)
+    assert mmr_select(E, q, blen, 1.0, 6, 1000) == [0, 1, 3]
+    assert ofu.mmr_selection(E, q, blen.tolist(), 1.0, 6, 1000) == [0, 1, 3]
+    assert mmr_select(E, q, blen, 1.0, 6, 100) == [0]              # budget below the first pick: it still goes in
+    assert mmr_select(E, q, blen, 1.0, 6, 1010) == [0, 1, 3, 5]
+    assert mmr_select(E, q, blen, 1.0, 2, 10 ** 6) == [0, 1]
+    assert mmr_select(E, q, blen, 1.0, None, None) == [0, 1, 2, 3, 4, 5]
 
 
 def test_csc_large_single_term_and_many_rows(engine):
