@@ -89,11 +89,15 @@ class ShardedFlatSearcher:
             self.I_all = self._pack_all[:, :m].view(self.world, nq, k)
             self.D_all = self._pack_all[:, m:].view(torch.float32)[:, :m].view(self.world, nq, k)
             self.out_packed = out if out is not None else torch.zeros(words, dtype=torch.int64, device=device)
-            # gloo cannot move GPU tensors by itself: torch stages them through pinned host memory on
-            # side streams of its own.  RAG_GLOO_STAGE=1 does that staging here instead, on the
-            # searcher's stream (DESIGN.md section 5 says why the switch exists).
+            # gloo cannot move GPU tensors by itself: torch's ProcessGroupGloo stages them through
+            # pinned temporaries on side streams of its own and synchronises those from a worker
+            # thread.  With several ranks on ONE card (the one-GPU rehearsal of bench.py) that path
+            # takes 0.02-0.5 s per collective even with every stage ordered on one stream (measured
+            # twice), so the packed lists are staged here instead, on the
+            # searcher's stream: 0.6 ms per step.  RAG_GLOO_STAGE=0 selects torch's own path.
+            # RCCL (the real transport) takes device tensors directly and never comes here.
             self._stage = (self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "gloo"
-                           and os.environ.get("RAG_GLOO_STAGE", "0") == "1")
+                           and os.environ.get("RAG_GLOO_STAGE", "1") == "1")
             if self._stage:
                 self._h_pack = torch.zeros(words, dtype=torch.int64).pin_memory()
                 self._h_all = torch.zeros((self.world, words), dtype=torch.int64).pin_memory()
