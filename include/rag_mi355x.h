@@ -101,6 +101,11 @@ int rag_flat_add_dev(rag_flat_t* h, int64_t n, const float* x_dev, void* stream)
 int rag_flat_add_synthetic(rag_flat_t* h, int64_t n, uint64_t seed, int64_t first_global_row);
 /* index.ntotal: vector_storage.py:193. */
 int64_t rag_flat_ntotal(const rag_flat_t* h);
+/* Text naming the kernels and launch shape that served the handle's last search ("stream list G1 RG4
+ * KS1 NB2 blocks256", "wide filter ...", "tile list ...", "scan"): lets tests and benches assert the
+ * dispatch instead of assuming it.  Valid until the next search on the handle.  No counterpart in
+ * the reference. */
+const char* rag_flat_last_kernel(const rag_flat_t* h);
 /* index.d */
 int rag_flat_dim(const rag_flat_t* h);
 /* index.reset() (rebuild_faiss_index creates a fresh index, :146,151). */

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rag_flat_add_synthetic": (C.c_int, [_p, _i64, C.c_uint64, _i64]),
     "rag_flat_ntotal": (_i64, [_p]),
     "rag_flat_dim": (C.c_int, [_p]),
+    "rag_flat_last_kernel": (C.c_char_p, [_p]),
     "rag_flat_reset": (C.c_int, [_p]),
     "rag_flat_search": (C.c_int, [_p, _i64, _p, C.c_int, _p, _p]),
     "rag_flat_search_dev": (C.c_int, [_p, _i64, _p, C.c_int, _p, _p, _i64, _p]),

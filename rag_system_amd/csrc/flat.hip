@@ -675,6 +675,7 @@ struct rag_flat {
     hipStream_t last_stream = nullptr;
     bool last_stream_valid = false;
     hipEvent_t order_ev = nullptr;
+    char last_kernel[96] = "";   // which kernels served the last search (rag_flat_last_kernel)
     std::mutex mu;
 };
 
@@ -980,7 +981,25 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     StreamPlan small_probe;
     const bool small_stream = opt.mfma_min_nq <= 0 && nq < mfma_min_nq && k <= 128 &&
                               stream_plan(n, nq, 1, dch, bf, false, 0, 1, &small_probe);
-    if ((nq >= mfma_min_nq || small_stream) && nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan)) {
+    // The LDS-resident lists of the tile kernel stop fitting at k ~ 122 (flat_mfma_kernel.h smem_need);
+    // the stream kernel keeps its lists in registers and serves k <= 128 for up to 8 queries per pass, so
+    // such batches go through it in chunks of 8 instead of falling to the scan kernel's query pairs.
+    const bool plan_ok = nq <= INT_MAX && mfma_plan(n, nq, k, bf, &plan);
+    if (!plan_ok && k <= 128 && nq > 8 && opt.mfma_min_nq <= 0 && nq >= mfma_min_nq) {
+        StreamPlan probe8;
+        if (stream_plan(n, 8, k, dch, bf, false, 0, 1, &probe8)) {
+            for (int64_t c0 = 0; c0 < nq; c0 += 8) {
+                const int64_t cn = std::min<int64_t>(8, nq - c0);
+                rc = search_device(h, cn, q_dev + c0 * h->d, k, D_dev + c0 * k, I_dev + c0 * k, id_base, st);
+                if (rc) return rc;
+            }
+            return RAG_OK;
+        }
+    }
+    StreamPlan sp_only;
+    const bool stream_list_ok = !plan_ok && k <= 128 && nq <= 8 && opt.mfma_min_nq <= 0 &&
+                                stream_plan(n, nq, k, dch, bf, false, 0, 1, &sp_only);
+    if ((nq >= mfma_min_nq || small_stream) && (plan_ok || stream_list_ok)) {
         // Filter mode for larger k on large shards: a 1/FILTER_STEP sample of the row tiles gives
         // each query a threshold (its j-th best sample score), one pass appends every row at or
         // above it, and the top-k of the few hundred appended rows is the exact result.  With
@@ -1009,13 +1028,15 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         WidePlan wp;
         // from 9 queries: 10M x 384, nq 16: 2.57-2.67 ms against 2.76 for the stream kernel (k = 100: 2.67 / 3.26)
         const int64_t wide_min_nq = opt.wide_min_nq > 0 ? opt.wide_min_nq : 9;
-        const bool wide = nq >= wide_min_nq && opt.mfma_filter_k <= 1 && n >= opt.mfma_filter_min_rows &&
+        // (filter mode and the wide kernel, which only has sample and filter passes, need the list-mode
+        // tile kernel as their redo path)
+        const bool wide = plan_ok && nq >= wide_min_nq && opt.mfma_filter_k <= 1 && n >= opt.mfma_filter_min_rows &&
                           wide_plan(n, nq, dch, bf, j, cap, FILTER_STEP, &wp);
         const int64_t filter_k = opt.mfma_filter_k > 0 ? opt.mfma_filter_k
                                  : wide                ? 1
                                  : stream_ok           ? (nq > 8 ? 24 : (nq >= 4 ? 65 : 129))
                                                        : (nq <= 128 ? 16 : 33);
-        const bool filter = k >= filter_k && n >= opt.mfma_filter_min_rows &&
+        const bool filter = plan_ok && k >= filter_k && n >= opt.mfma_filter_min_rows &&
                             mfma_plan(std::max<long long>(1, n / FILTER_STEP), nq, j, bf, &ps) &&
                             mfma_plan_filter(n, nq, bf, cap, &pf);
         // batches of up to 16 queries: the register-fed stream kernel (flat_stream.hip) takes the pass
@@ -1023,7 +1044,8 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         StreamPlan sp, sps;
         const bool stream = !wide && stream_plan(n, nq, k, dch, bf, filter, cap, 1, &sp) &&
                             (!filter || stream_plan(n, nq, 1, dch, bf, false, 0, FILTER_STEP, &sps));
-        int64_t need = nq * plan.nlists * k;
+        if (!plan_ok && !stream) return fail(RAG_ERR_HIP, "dispatch: neither the tile nor the stream kernel serves this shape");
+        int64_t need = plan_ok ? nq * plan.nlists * k : 0;
         if (stream && !filter) need = std::max<int64_t>(need, nq * (int64_t)sp.nlists * k);
         if (stream && filter) need = std::max<int64_t>(need, nq * (int64_t)sps.nlists);
         if (wide && filter) need = std::max<int64_t>(need, nq * (int64_t)wp.wpad);
@@ -1059,6 +1081,9 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         const int ldw = ld * h->esz / 4;
         merge_fn_t mf = pick_merge(KS, h->metric);
         if (!filter) {
+            snprintf(h->last_kernel, sizeof h->last_kernel, "%s list G%d RG%d KS%d NB%d blocks%d",
+                     stream ? "stream" : "tile", stream ? sp.G : 0, stream ? sp.RG : 0, stream ? sp.KS : plan.KS,
+                     stream ? sp.NB : plan.NS, stream ? sp.blocks : plan.nlists);
             if (stream)
                 rc = stream_launch(sp, h->x, (long long)n, dch, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
                                    h->ws_qn, st);
@@ -1078,6 +1103,8 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         // j-th largest of those is the threshold: it equals the j-th best sampled row unless two of
         // the best j fell to one wave / block, which only lowers it.  The tile kernel keeps j per list.
         ps.tile_step = FILTER_STEP;
+        snprintf(h->last_kernel, sizeof h->last_kernel, "%s filter step%d j%d cap%d", wide ? "wide" : (stream ? "stream" : "tile"),
+                 FILTER_STEP, j, cap);
         if (wide) {
             rc = wide_sample(wp, h->x, (long long)n, dch, Qw, (int)nq, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
                              st);
@@ -1151,6 +1178,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             const char* Qb = bf ? reinterpret_cast<const char*>(h->ws_qb) : reinterpret_cast<const char*>(qf);
             const size_t qrow = (size_t)ld * h->esz;
             merge_fn_t mf4 = pick_merge(4, h->metric);
+            snprintf(h->last_kernel, sizeof h->last_kernel, "stream list KS4 (four queries per pass)");
             for (int64_t q0 = 0; q0 < nq; q0 += 4) {
                 const int cn = (int)std::min<int64_t>(4, nq - q0);
                 if (!stream_plan(n, cn, k, dch, bf, false, 0, 1, &sp4)) return fail(RAG_ERR_HIP, "stream plan changed");
@@ -1177,6 +1205,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     // waves per CU (benchmarks/run_scan_threads_ab.sh): fp32 rows stream fastest with 12 (10M x 384:
     // 2.19 ms against 2.215 ms with 16; 14 and 10 are slower), bfloat16 rows need 16 to cover the
     // unpacking (2.28 ms against 2.63 ms with 12)
+    snprintf(h->last_kernel, sizeof h->last_kernel, "scan");
     int64_t blocks = opt.scan_blocks > 0 ? opt.scan_blocks : (int64_t)num_cus() * (bf ? 4 : 3);
     int Rsel = (opt.scan_rows == 2 || opt.scan_rows == 8) ? (int)opt.scan_rows : 4;
 
@@ -1375,6 +1404,7 @@ int rag_flat_add_synthetic(rag_flat_t* h, int64_t n, uint64_t seed, int64_t firs
 }
 
 int64_t rag_flat_ntotal(const rag_flat_t* h) { return h ? h->ntotal : -1; }
+const char* rag_flat_last_kernel(const rag_flat_t* h) { return h ? h->last_kernel : ""; }
 int rag_flat_dim(const rag_flat_t* h) { return h ? h->d : -1; }
 
 int rag_flat_reset(rag_flat_t* h) {

@@ -73,6 +73,10 @@ class _HipFlatBackend:
     def reset(self):
         _lib.check(self._lib.rag_flat_reset(self._h), self._lib)
 
+    def last_kernel(self):
+        """Which kernels served the last search on this handle (rag_flat_last_kernel)."""
+        return (self._lib.rag_flat_last_kernel(self._h) or b"").decode()
+
     def to_host(self, first=0, n=None):
         n = self.ntotal - first if n is None else n
         out = np.empty((n, self.d), dtype=np.float32)
