@@ -121,6 +121,18 @@ int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, 
  * shard when the corpus is row-sharded over ranks). */
 int rag_flat_search_dev(rag_flat_t* h, int64_t nq, const float* q_dev, int k,
                         float* D_dev, int64_t* I_dev, int64_t id_base, void* stream);
+/* rag_flat_search_dev for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs, outputs and
+ * results as rag_flat_search_dev (same kernels), but its workspaces -- padded queries, query norms, the
+ * per-block candidate lists -- live in a static 8.4 MiB device array of the library instead of buffers
+ * grown on demand, and it calls no hipMalloc / hipFree / allocating routine.  Limits, rejected with
+ * RAG_ERR_INVALID_ARG / RAG_ERR_UNSUPPORTED: nq <= 8, k <= 128, at least 16 rows, rows short enough for the
+ * LDS-resident queries (any d <= 2048 qualifies), no rows still staged on the host by rag_flat_add (search
+ * once with the allocating entry point, or add in bulk), L2 only once the row norms exist (any earlier
+ * allocating search computes them).  Every call on a GPU shares that GPU's array: calls that overlap on
+ * one GPU (two streams, two handles) race; issue them on one stream or serialise them. */
+int rag_flat_search_dev_noalloc(rag_flat_t* h, int64_t nq, const float* q_dev, int k,
+                                float* D_dev, int64_t* I_dev, int64_t id_base, void* stream);
 /* Rows [first, first+n) back to the host as float32 (faiss.write_index,
  * vector_storage.py:231, needs the raw vectors). */
 int rag_flat_copy_to_host(rag_flat_t* h, int64_t first, int64_t n, float* out);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rag_flat_reset": (C.c_int, [_p]),
     "rag_flat_search": (C.c_int, [_p, _i64, _p, C.c_int, _p, _p]),
     "rag_flat_search_dev": (C.c_int, [_p, _i64, _p, C.c_int, _p, _p, _i64, _p]),
+    "rag_flat_search_dev_noalloc": (C.c_int, [_p, _i64, _p, C.c_int, _p, _p, _i64, _p]),
     "rag_flat_copy_to_host": (C.c_int, [_p, _i64, _i64, _p]),
     "rag_topk_merge_dev": (C.c_int, [C.c_int, C.c_int, _i64, C.c_int, _p, _p, _p, _p, _p]),
     "rag_topk_merge_strided_dev": (C.c_int, [C.c_int, C.c_int, _i64, C.c_int, _p, _p, _i64, _i64, _p, _p, _p]),

@@ -40,6 +40,7 @@ struct Options {
     int64_t sparse_topk_lists = 0;  // 1: BM25 / TF-IDF top-k always by the list kernels (no threshold path)
 };
 Options& options();
+int flat_init_scratch();  // flat.hip: address of the no-allocation entry point's scratch on the current device
 
 }  // namespace rag
 

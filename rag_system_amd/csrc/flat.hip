@@ -29,9 +29,34 @@
 #include <cstring>
 #include <vector>
 
+// ---------------------------------------------------------------- scratch of the no-allocation entry point
+// rag_flat_search_dev_noalloc (callers that cannot allocate: HIP graph capture, tight serving loops)
+// keeps its padded queries, query norms and per-block candidate lists here instead of in workspaces
+// grown with hipMalloc.  One array per GPU the library runs on, held until the process ends.  The name
+// below is a host-side stand-in, not a device address: host code only ever uses the pointer that
+// hipGetSymbolAddress returned for the device (g_scratch_ptr, set by rag::flat_init_scratch()).
+#define RAG_NOALLOC_MAX_NQ 8
+#define RAG_NOALLOC_MAX_K 128
+namespace {
+constexpr size_t NA_Q_BYTES = (size_t)RAG_NOALLOC_MAX_NQ * 8192 * 4;  // fp32 queries, padded rows (d <= 8192)
+constexpr size_t NA_QB_BYTES = NA_Q_BYTES / 2;                        // the same as bfloat16
+constexpr size_t NA_QN_BYTES = 256;                                   // ||q||^2 (L2)
+constexpr size_t NA_LIST_ENTRIES = (size_t)1 << 20;                   // nq * blocks * k <= 8 * 1024 * 128
+constexpr size_t NA_OFF_QB = NA_Q_BYTES;
+constexpr size_t NA_OFF_QN = NA_OFF_QB + NA_QB_BYTES;
+constexpr size_t NA_OFF_KEY = NA_OFF_QN + NA_QN_BYTES;
+constexpr size_t NA_OFF_ID = NA_OFF_KEY + NA_LIST_ENTRIES * 4;
+constexpr size_t NA_SCRATCH_BYTES = NA_OFF_ID + NA_LIST_ENTRIES * 4;  // 8.4 MiB
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
+
 namespace {
 
 using namespace rag;
+
+// per device: the address hipGetSymbolAddress gave for `scratch` with that device current
+int g_scratch_dev = -1;
+unsigned char* g_scratch_ptr = nullptr;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1268,7 +1293,83 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     return RAG_OK;
 }
 
+// The no-allocation search: the stream kernel in list mode (<= 8 queries, k <= 128) + the merge of its
+// block lists, workspaces inside `ws` (this device's copy of the static scratch array).  Nothing here
+// allocates or frees; every byte of scratch a kernel reads was written earlier in the same call
+// (queries by pad_queries_kernel, norms by the norm kernel, every block writes all k entries of each
+// of its lists), so nothing has to start at zero and a call does not depend on the previous one.
+int search_device_noalloc(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_dev, long long* I_dev,
+                          int64_t id_base, hipStream_t st, unsigned char* ws) {
+    const int64_t n = h->ndev;
+    if (n == 0) {
+        const long long total = nq * k;
+        fill_pad_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            D_dev, I_dev, total, h->metric == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX);
+        RAG_HIP(hipGetLastError());
+        return RAG_OK;
+    }
+    if (n > (int64_t)INT_MAX - 8)
+        return fail(RAG_ERR_UNSUPPORTED, "more than 2^31-9 rows in one shard (%lld)", (long long)n);
+    const bool bf = h->dtype == RAG_DTYPE_BF16;
+    const int ld = h->ld;
+    const int dch = ld * h->esz / 16;
+    if (h->metric == RAG_METRIC_L2 && h->norm_valid < n)
+        return fail(RAG_ERR_UNSUPPORTED,
+                    "rag_flat_search_dev_noalloc: the L2 row norms of %lld rows are not computed yet (they live in "
+                    "allocated memory): run one rag_flat_search[_dev] after adding rows",
+                    (long long)(n - h->norm_valid));
+    StreamPlan sp;
+    if (!stream_plan(n, nq, k, dch, bf, false, 0, 1, &sp))
+        return fail(RAG_ERR_UNSUPPORTED,
+                    "rag_flat_search_dev_noalloc: shape not served by the stream kernel (n=%lld rows [>= 16], d=%d)",
+                    (long long)n, h->d);
+    if ((size_t)nq * (size_t)sp.nlists * (size_t)k > NA_LIST_ENTRIES)
+        return fail(RAG_ERR_UNSUPPORTED, "rag_flat_search_dev_noalloc: %lld x %d lists of %d entries exceed the scratch",
+                    (long long)nq, sp.nlists, k);
+    float* ws_q = reinterpret_cast<float*>(ws);
+    unsigned short* ws_qb = reinterpret_cast<unsigned short*>(ws + NA_OFF_QB);
+    float* ws_qn = reinterpret_cast<float*>(ws + NA_OFF_QN);
+    float* ws_key = reinterpret_cast<float*>(ws + NA_OFF_KEY);
+    int* ws_id = reinterpret_cast<int*>(ws + NA_OFF_ID);
+    const bool q_direct = !bf && ld == h->d && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0;
+    const float* qf = q_dev;
+    if (!q_direct) {
+        const long long total = nq * ld;
+        pad_queries_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(q_dev, ws_q, bf ? ws_qb : nullptr, nq, h->d, ld);
+        RAG_HIP(hipGetLastError());
+        qf = ws_q;
+    }
+    if (h->metric == RAG_METRIC_L2) {
+        int rc = mfma_row_norms(qf, ld, false, 0, nq, ws_qn, st);
+        if (rc) return rc;
+    }
+    const void* Qw = bf ? static_cast<const void*>(ws_qb) : static_cast<const void*>(qf);
+    snprintf(h->last_kernel, sizeof h->last_kernel, "stream list G%d RG%d KS%d NB%d blocks%d (noalloc)", sp.G, sp.RG, sp.KS,
+             sp.NB, sp.blocks);
+    int rc = stream_launch(sp, h->x, (long long)n, dch, Qw, (int)nq, k, h->metric, ws_key, ws_id, h->xnorm, ws_qn, st);
+    if (rc) return rc;
+    pick_merge(ks_for(k), h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(ws_key, ws_id, sp.nlists, k, D_dev, I_dev,
+                                                                            (long long)id_base, k, 0, nullptr);
+    RAG_HIP(hipGetLastError());
+    return RAG_OK;
+}
+
 }  // namespace
+
+namespace rag {
+// Called by rag_init() with the selected device current, once per process (one process per GPU).
+int flat_init_scratch() {
+    int dev = -1;
+    RAG_HIP(hipGetDevice(&dev));
+    if (g_scratch_ptr != nullptr && g_scratch_dev == dev) return RAG_OK;
+    unsigned char* p = nullptr;
+    RAG_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+    if (p == nullptr) return fail(RAG_ERR_HIP, "hipGetSymbolAddress(scratch) returned NULL");
+    g_scratch_ptr = p;
+    g_scratch_dev = dev;
+    return RAG_OK;
+}
+}  // namespace rag
 
 // ---------------------------------------------------------------- C ABI
 
@@ -1432,6 +1533,32 @@ int rag_flat_search_dev(rag_flat_t* h, int64_t nq, const float* q_dev, int k, fl
     rc = order_after_previous(h, st);
     if (rc) return rc;
     return search_device(h, nq, q_dev, k, D_dev, reinterpret_cast<long long*>(I_dev), id_base, st);
+}
+
+int rag_flat_search_dev_noalloc(rag_flat_t* h, int64_t nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev,
+                                int64_t id_base, void* stream) {
+    RAG_REQUIRE_INIT();
+    if (!h || nq < 0 || (nq > 0 && (!q_dev || !D_dev || !I_dev)))
+        return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
+    if (nq > RAG_NOALLOC_MAX_NQ)
+        return fail(RAG_ERR_INVALID_ARG, "rag_flat_search_dev_noalloc: nq=%lld beyond its maximum %d", (long long)nq,
+                    RAG_NOALLOC_MAX_NQ);
+    if (k < 1 || k > RAG_NOALLOC_MAX_K)
+        return fail(RAG_ERR_INVALID_ARG, "rag_flat_search_dev_noalloc: k=%d out of range [1,%d]", k, RAG_NOALLOC_MAX_K);
+    if (nq == 0) return RAG_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->staged.empty())
+        return fail(RAG_ERR_UNSUPPORTED,
+                    "rag_flat_search_dev_noalloc: %lld added rows are still staged on the host (flushing them "
+                    "allocates): call rag_flat_search[_dev] once, or add rows in bulk",
+                    (long long)(h->staged.size() / h->d));
+    int dev = -1;
+    RAG_HIP(hipGetDevice(&dev));
+    if (g_scratch_ptr == nullptr || dev != g_scratch_dev)
+        return fail(RAG_ERR_NOT_INIT, "rag_flat_search_dev_noalloc: no scratch address for device %d (rag_init ran on %d)",
+                    dev, g_scratch_dev);
+    return search_device_noalloc(h, nq, q_dev, k, D_dev, reinterpret_cast<long long*>(I_dev), id_base,
+                                 (hipStream_t)stream, g_scratch_ptr);
 }
 
 int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I) {

@@ -75,6 +75,10 @@ int rag_init(int device_id) {
                          device_id, prop.gcnArchName);
     rag::g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     RAG_HIP(hipStreamCreateWithFlags(&rag::g_stream, hipStreamNonBlocking));
+    {
+        const int rc = rag::flat_init_scratch();  // with device_id current
+        if (rc) return rc;
+    }
     rag::g_dev = device_id;
     rag::g_init = true;
     return RAG_OK;
