@@ -162,7 +162,8 @@ int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double
  * append buffers, and how densely the rows are sampled for the thresholds),
  * "stream_max_nq" (-1: never), "stream_rg", "stream_bpc", "stream_nb" (register-fed kernel for up to 16 queries),
  * "wide_max_nq" (-1: never), "wide_min_nq", "wide_wpb" (register-fed kernel for 9..64 queries),
- * "sparse_topk_lists" (1: BM25 / TF-IDF top-k by the list kernels only, no threshold path).
+ * "sparse_topk_lists" (1: BM25 / TF-IDF top-k by the list kernels only, no threshold path),
+ * "sparse_fused" (0: BM25 / TF-IDF scoring by one launch per query term instead of the fused kernel).
  * Unknown name -> RAG_ERR_INVALID_ARG.  The selected ids never depend on them; scores are
  * bit-identical within one kernel and equal up to the fp32 summation order across kernels
  * (tests/test_flat_gpu.py, test_flat_stream_gpu.py, test_flat_wide_gpu.py). */

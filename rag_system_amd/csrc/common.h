@@ -38,6 +38,7 @@ struct Options {
     int64_t wide_min_nq = 0;    // ... from this size (0 = auto: 9; smaller batches and small shards stay with the stream kernel)
     int64_t wide_wpb = 0;       // waves per block of that kernel (0 = auto by LDS use)
     int64_t sparse_topk_lists = 0;  // 1: BM25 / TF-IDF top-k always by the list kernels (no threshold path)
+    int64_t sparse_fused = 1;       // 0: BM25 / TF-IDF scoring by one launch per query term (the pre-fusion path)
 };
 Options& options();
 int flat_init_scratch();  // flat.hip: address of the no-allocation entry point's scratch on the current device

@@ -112,6 +112,7 @@ int rag_set_option(const char* name, int64_t value) {
     else if (!std::strcmp(name, "wide_min_nq")) o.wide_min_nq = value;
     else if (!std::strcmp(name, "wide_wpb")) o.wide_wpb = value;
     else if (!std::strcmp(name, "sparse_topk_lists")) o.sparse_topk_lists = value;
+    else if (!std::strcmp(name, "sparse_fused")) o.sparse_fused = value;
     else return rag::fail(RAG_ERR_INVALID_ARG, "unknown option '%s'", name);
     return RAG_OK;
 }

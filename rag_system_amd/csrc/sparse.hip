@@ -152,6 +152,7 @@ constexpr int SPANS = 1024;
 constexpr size_t PIN_BYTES = 64 << 10;
 // rag_tfidf_query keeps the top-k at [0, 2K) / [32K, 34K) like every top-k call and adds:
 constexpr size_t PIN_Q_ROWS = 4 << 10, PIN_Q_RANKS = 36 << 10, PIN_Q_SCORES = 44 << 10;  // 8 KiB each (RANK_MAXQ x 8)
+constexpr size_t PIN_FLAG = 60 << 10;  // fused selection: 1 = its buffer overflowed, rerun with the list kernels
 constexpr int THR_CAP = 8192;
 
 __global__ __launch_bounds__(256) void span_max_kernel(const double* __restrict__ score, long long n,
@@ -431,6 +432,601 @@ __global__ void gather_kernel(const double* __restrict__ score, int nq, const lo
     if (i < nq) out[i] = score[qrow[i]];
 }
 
+
+// ================================================================ fused path (one launch per scoring)
+// The per-term launches above are launch-bound (a query of 3-8 terms is 5 us per term for ~1 us of
+// traffic each).  Fused path: the rows are cut into blocks of SP_R, one workgroup owns one block, keeps
+// its SP_R scores in LDS and walks the query terms IN ORDER over its slice of each term's postings
+// (postings ascend by row within a term; the slice bounds of frequent terms come from a skip table built
+// with the index, rare terms are scanned whole by every workgroup).  A row's additions therefore happen
+// in query-term order with exactly the float64 operations of the per-term kernels: bit-identical scores,
+// no atomics, no read-modify-write traffic to HBM -- 12-16 bytes per posting instead of 28-32.
+// The selection kernel behind it fuses what used to be six launches (span maxima, threshold, compaction,
+// exact selection, rank histogram, rank prefix): every workgroup derives the threshold from the span
+// maxima, compacts its own rows and bins them for the rank query; the workgroup that finishes last
+// (one ticket, agent-scope release / acquire) selects, completes ties and writes the results -- straight
+// into pinned host memory, so a call is two launches and one synchronisation.
+constexpr int SP_R = 1024;            // rows owned by one workgroup
+constexpr int SP_T = 256;             // threads per workgroup
+constexpr int SP_SUB = SP_R / 64;     // 64-row sub-spans per workgroup; their maxima feed the threshold
+constexpr int SP_MAXT = 64;           // query terms per launch (longer queries: several launches, scores carried in HBM)
+constexpr long long SP_FREQ_MIN = 1024;  // terms with at least this many postings get a row of the skip table
+// counters: [0] scores appended, [1] unused, [2] rows scoring exactly T, [3] second-level ticket of the selection
+// kernel; first-level tickets on cache lines of their own: one word takes ~88 returning atomics per
+// microsecond, a thousand workgroups on one word were 11 us.  The scoring kernel's own tickets follow.
+constexpr int SP_TGRP = 32;
+constexpr int SP_TICKET0 = 32;                               // selection kernel: SP_TGRP words, stride 32 ints
+constexpr int SP_TICKET1 = SP_TICKET0 + SP_TGRP * 32;         // scoring kernel: SP_TGRP + 1 words, stride 32 ints
+constexpr int SP_NCOUNTERS = SP_TICKET1 + (SP_TGRP + 1) * 32;
+constexpr int SP_ZERO_PER_CALL = SP_TICKET1;                  // what the scoring kernel clears for the selection kernel
+constexpr int SP_HREP = 32;                                   // replicas of the rank histogram (workgroup % SP_HREP)
+
+struct SpTerms {
+    int n;
+    int freq[SP_MAXT];          // row of the skip table, or -1: rare term
+    long long begin[SP_MAXT];   // postings [begin, end) of the term
+    long long end[SP_MAXT];
+    double w[SP_MAXT];          // BM25: idf of the term; TF-IDF: the query weight
+};
+
+template <bool BM25>
+__global__ __launch_bounds__(SP_T) void sparse_score_kernel(
+    const SpTerms qt, const int* __restrict__ row, const double* __restrict__ val, const int* __restrict__ skip,
+    long long skip_ld, const int* __restrict__ doc_len, double avgdl, double k1, double b, double k1p1, double omb,
+    long long n_rows, double* __restrict__ score, double* __restrict__ wmax, double* __restrict__ bmax, int accumulate,
+    int* __restrict__ counters, int n_counters, unsigned long long* __restrict__ hist, int n_hist,
+    const long long* __restrict__ qrow_host, long long* __restrict__ qrow_dev, int n_qrow, int thr_G, int thr_k,
+    int thr_per_block, double* __restrict__ thr_out) {
+    __shared__ double s[SP_R];
+    __shared__ int flag[2];
+    __shared__ double t4s[BM25 ? SP_R : 1];
+    __shared__ long long rng[SP_MAXT][2];
+    __shared__ double sub[SP_SUB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long lo = (long long)blockIdx.x * SP_R;
+    const int cnt = (int)(n_rows - lo < SP_R ? n_rows - lo : SP_R);
+    if (blockIdx.x == 0) {  // per-call set-up of what the selection kernel consumes (it runs behind this launch)
+        for (int i = tid; i < n_counters; i += SP_T) counters[i] = 0;
+        for (int i = tid; i < n_hist; i += SP_T) hist[i] = 0ULL;
+        for (int i = tid; i < n_qrow; i += SP_T) qrow_dev[i] = qrow_host[i];
+    }
+    for (int r = tid; r < SP_R; r += SP_T) {
+        s[r] = (accumulate && r < cnt) ? score[lo + r] : 0.0;
+        if (BM25) {
+            double t4 = 0.0;
+            if (r < cnt) {  // the row's part of the denominator, the same operations as bm25_term_kernel
+                const double t1 = b * (double)doc_len[lo + r];
+                const double t2 = t1 / avgdl;
+                const double t3 = omb + t2;
+                t4 = k1 * t3;
+            }
+            t4s[r] = t4;
+        }
+    }
+    if (tid < qt.n) {
+        const int f = qt.freq[tid];
+        long long pb = qt.begin[tid], pe = qt.end[tid];
+        if (f >= 0) {
+            const int* sk = skip + (long long)f * skip_ld + blockIdx.x;
+            pe = pb + sk[1];
+            pb = pb + sk[0];
+        }
+        rng[tid][0] = pb;
+        rng[tid][1] = pe;
+    }
+    __syncthreads();
+    for (int i = 0; i < qt.n; ++i) {
+        const long long pb = rng[i][0], pe = rng[i][1];
+        const double w = qt.w[i];
+        const bool sliced = qt.freq[i] >= 0;
+        for (long long p = pb + tid; p < pe; p += SP_T) {
+            const int r = row[p] - (int)lo;
+            if (sliced || (r >= 0 && r < cnt)) {
+                const double v = val[p];
+                if (BM25) {
+                    const double num = v * k1p1;
+                    const double den = v + t4s[r];
+                    const double frac = num / den;
+                    const double c = w * frac;
+                    s[r] = s[r] + c;
+                } else {
+                    const double prod = w * v;
+                    s[r] = s[r] + prod;
+                }
+            }
+        }
+        __syncthreads();  // a row's additions happen in query-term order
+    }
+#pragma unroll
+    for (int j = 0; j < SP_R / SP_T; ++j) {
+        const int r = j * SP_T + tid;
+        const double v = s[r];
+        if (r < cnt) score[lo + r] = v;
+        double m = r < cnt ? v : -DBL_MAX;
+        if (!(m > -DBL_MAX)) m = -DBL_MAX;  // NaN never wins
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double o = __shfl_xor(m, d, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) {  // write-through (sc1): read by the last workgroup of this launch, see below
+            __hip_atomic_store(&wmax[(long long)blockIdx.x * SP_SUB + j * (SP_T / 64) + wid], m, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            sub[j * (SP_T / 64) + wid] = m;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double m = -DBL_MAX;
+        for (int i = 0; i < SP_SUB; ++i) m = sub[i] > m ? sub[i] : m;
+        __hip_atomic_store(&bmax[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (thr_G <= 0) return;  // no selection behind this launch (or not its last launch)
+
+    // ---- threshold of the selection kernel, computed ONCE by the workgroup that finishes last (every
+    // workgroup of the selection kernel doing it for itself cost 10-58 us): T = the thr_k-th largest of
+    // thr_G group maxima.  k groups hold a score >= T each, so at least k rows score >= T; for scores in no
+    // particular order few more do.  Hand-off as in sparse_select_kernel (sc1 stores, drained, one ticket).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int nb = (int)gridDim.x, g = (int)blockIdx.x % SP_TGRP;
+        const int gsize = (nb - g + SP_TGRP - 1) / SP_TGRP;
+        int last = 0;
+        const int t = __hip_atomic_fetch_add(&counters[SP_TICKET1 + g * 32], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gsize - 1) {
+            const int groups = nb < SP_TGRP ? nb : SP_TGRP;
+            const int t2 = __hip_atomic_fetch_add(&counters[SP_TICKET1 + SP_TGRP * 32], 1, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+            last = (t2 == groups - 1) ? 1 : 0;
+        }
+        flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0] == 0) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // everyone has arrived: the ticket words go back to zero for the next launch
+    if (tid <= SP_TGRP) __hip_atomic_store(&counters[SP_TICKET1 + tid * 32], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    double* gv = s;  // thr_G <= SP_R doubles
+    const double* gmax = thr_per_block ? bmax : wmax;
+    const long long n_g = thr_per_block ? (long long)gridDim.x : (long long)gridDim.x * SP_SUB;
+    const long long gs = (n_g + thr_G - 1) / thr_G;
+    for (int t = tid; t < thr_G; t += SP_T) {
+        double m = -DBL_MAX;
+        const long long s0 = (long long)t * gs;
+        const long long s1 = s0 + gs < n_g ? s0 + gs : n_g;
+        for (long long sp = s0; sp < s1; ++sp) {
+            const double v = gmax[sp];
+            m = v > m ? v : m;
+        }
+        gv[t] = m;
+    }
+    __syncthreads();
+    // rank by counting (broadcast LDS reads, eight in flight; no barrier per step)
+    for (int t = tid; t < thr_G; t += SP_T) {
+        const double v = gv[t];
+        int ahead = 0;
+        for (int j = 0; j < thr_G; j += 8) {
+            double o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = gv[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ahead += (o[u] > v || (o[u] == v && j + u < t)) ? 1 : 0;
+        }
+        if (ahead == thr_k - 1) thr_out[0] = v;
+    }
+}
+
+// Dynamic LDS of sparse_select_kernel (bytes): [gv: G doubles][uk, ks: nq doubles each][ur, rs: nq int64 each]
+// [po: nq ints][hh: nq+1 u32][hl: nq+1 u64][sk: SP_SORT doubles][si: SP_SORT ints][ahead_of: 512 ints][mk: 3*KS*64 doubles]
+// [mi: 3*KS*64 ints][misc: 16 ints]
+constexpr int SP_SORT = 1024;  // candidates the last workgroup sorts in LDS (more: list merge)
+constexpr int SP_COUNT = 384;
+  // ... and up to this many it ranks by counting instead
+__host__ __device__ inline size_t sp_select_smem(int G, int nq, int KS) {
+    size_t o = (size_t)G * 8 + (size_t)nq * 32;
+    o += (((size_t)nq * 4 + 7) & ~(size_t)7) + ((((size_t)nq + 1) * 4 + 7) & ~(size_t)7) + ((size_t)nq + 1) * 8;
+    o += (size_t)SP_SORT * 12 + 512 * 4;
+    o += (size_t)3 * KS * 64 * 12 + 64;
+    return o;
+}
+
+// Best-first (key descending, id ascending) bitonic sort of M = 2^x (key, id) pairs in LDS, M <= SP_SORT.
+__device__ __forceinline__ void lds_sort_pairs(double* sk, int* si, int M, int tid) {
+    for (int size = 2; size <= M; size <<= 1) {
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            for (int p = tid; p < M / 2; p += SP_T) {
+                const int i = ((p & ~(st - 1)) << 1) | (p & (st - 1));
+                const int j = i + st;
+                const bool best_first = (i & size) == 0;
+                const double ka = sk[i], kb = sk[j];
+                const int ia = si[i], ib = si[j];
+                const bool b_ahead = (kb > ka) || (kb == ka && ib < ia);
+                const bool a_ahead = (ka > kb) || (ka == kb && ia < ib);
+                if (best_first ? b_ahead : a_ahead) {
+                    sk[i] = kb; sk[j] = ka;
+                    si[i] = ib; si[j] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// thr[0]: the threshold left by the scoring launch.  G = 0 (no LDS for group maxima here).
+template <int KS>
+__global__ __launch_bounds__(SP_T) void sparse_select_kernel(
+    const double* __restrict__ score, long long n_rows, const double* __restrict__ thr, int G, int k,
+    double* __restrict__ buf_key, int* __restrict__ buf_id, int* __restrict__ eq_id, int* __restrict__ counters,
+    int nq, const long long* __restrict__ qrow, unsigned long long* __restrict__ hist, double* __restrict__ out_D,
+    long long* __restrict__ out_I, long long* __restrict__ out_rank, double* __restrict__ out_rowscore,
+    int* __restrict__ out_flag) {
+    extern __shared__ __align__(16) unsigned char sm[];
+    double* gv = reinterpret_cast<double*>(sm);
+    double* uk = gv + G;
+    double* ks = uk + nq;
+    long long* ur = reinterpret_cast<long long*>(ks + nq);
+    long long* rs = ur + nq;
+    int* po = reinterpret_cast<int*>(rs + nq);
+    unsigned int* hh = reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(po) + (((size_t)nq * 4 + 7) & ~(size_t)7));
+    unsigned long long* hl = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(hh) +
+                                                                   ((((size_t)nq + 1) * 4 + 7) & ~(size_t)7));
+    double* sk = reinterpret_cast<double*>(hl + nq + 1);
+    int* si = reinterpret_cast<int*>(sk + SP_SORT);
+    int* ahead_of = si + SP_SORT;  // 512 ints: SP_COUNT rounded up to a power of two
+    double* mk = reinterpret_cast<double*>(ahead_of + 512);
+    int* mi = reinterpret_cast<int*>(mk + 3 * KS * 64);
+    int* misc = mi + 3 * KS * 64;  // [0] last-workgroup flag, [1] filled, [2..5] per-wave counts
+    int* stage_i = mi;             // k <= 64*KS ints fit the 3*KS*64
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#ifdef RAG_SP_TIMING
+    unsigned long long ts[16];
+    int nts = 0;
+#define SP_STAMP() ts[nts++] = __builtin_readcyclecounter() * 0 + wall_clock64()
+#else
+#define SP_STAMP()
+#endif
+    SP_STAMP();
+
+    // every independent load first: this workgroup's scores, the queried rows and their scores, the maxima
+    double myv[SP_R / SP_T];
+#pragma unroll
+    for (int j = 0; j < SP_R / SP_T; ++j) {
+        const long long i = (long long)blockIdx.x * SP_R + j * SP_T + tid;
+        myv[j] = i < n_rows ? score[i] : -DBL_MAX;
+    }
+    for (int i = tid; i < nq; i += SP_T) {
+        const long long r = qrow[i];
+        ur[i] = r;
+        uk[i] = score[r];
+    }
+    for (int i = tid; i <= nq; i += SP_T) hh[i] = 0u;
+    const double T = thr[0];  // computed by the last workgroup of the scoring launch
+    __syncthreads();
+    SP_STAMP();
+
+    // ---- b. this workgroup's rows: scores > T appended, rows scoring exactly T remembered while they are few
+#pragma unroll
+    for (int j = 0; j < SP_R / SP_T; ++j) {
+        const long long i = (long long)blockIdx.x * SP_R + j * SP_T + tid;
+        const double v = myv[j];
+        const bool take = i < n_rows && v > T;
+        const unsigned long long m = __ballot(take);
+        if (m != 0ULL) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counters[0], __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (take) {
+                const int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+                if (slot < THR_CAP) {  // write-through (sc1) stores: the hand-off below needs no L2 write-back
+                    __hip_atomic_store(&buf_key[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&buf_id[slot], (int)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        const bool eq = i < n_rows && v == T;
+        const unsigned long long me = __ballot(eq);
+        if (me != 0ULL) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counters[2], __popcll(me));
+            base = __shfl(base, 0, 64);
+            if (eq) {
+                const int slot = base + __popcll(me & ((1ULL << lane) - 1ULL));
+                if (slot < THR_CAP) __hip_atomic_store(&eq_id[slot], (int)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+
+    SP_STAMP();
+    // ---- c. rank query: sort the queried (score, row) pairs best-first (every workgroup, in LDS), bin this
+    // workgroup's rows among them (rank_hist_kernel's rule)
+    if (nq > 0) {
+        // position of pair i = number of pairs ahead of it; the count is split over `parts` threads per pair so
+        // that all 256 threads work when there are few pairs (the loop is ~100 cycles per comparison)
+        int np2 = 1;
+        while (np2 < nq) np2 <<= 1;
+        const int parts = np2 >= SP_T ? 1 : SP_T / np2;
+        for (int i = tid; i < nq; i += SP_T) po[i] = 0;
+        __syncthreads();
+        for (int w0 = 0; w0 < nq; w0 += SP_T / parts) {
+            const int i = w0 + tid / parts, part = tid % parts;
+            if (i < nq) {
+                const double kk = uk[i];
+                const long long r = ur[i];
+                int pos = 0;
+                for (int j = part; j < nq; j += parts)  // a row queried twice: the earlier query sorts first
+                    pos += (pair_ahead(uk[j], ur[j], kk, r) || (uk[j] == kk && ur[j] == r && j < i)) ? 1 : 0;
+                if (pos) atomicAdd(&po[i], pos);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nq; i += SP_T) {
+            const int pos = po[i];
+            ks[pos] = uk[i];
+            rs[pos] = ur[i];
+        }
+        __syncthreads();
+#ifdef RAG_SP_TIMING
+        const unsigned long long t_prep = wall_clock64();
+#endif
+        // first sorted position whose pair is NOT ahead of (v, i): the searches of a thread's rows run side by
+        // side (independent LDS reads per step)
+        int blo[SP_R / SP_T], bhi[SP_R / SP_T];
+#pragma unroll
+        for (int j = 0; j < SP_R / SP_T; ++j) {
+            blo[j] = 0;
+            bhi[j] = nq;
+        }
+        for (int span = nq; span > 0; span >>= 1) {
+#pragma unroll
+            for (int j = 0; j < SP_R / SP_T; ++j) {
+                if (blo[j] < bhi[j]) {
+                    const long long i = (long long)blockIdx.x * SP_R + j * SP_T + tid;
+                    const int mid = (blo[j] + bhi[j]) >> 1;
+                    if (pair_ahead(ks[mid], rs[mid], myv[j], i)) blo[j] = mid + 1;
+                    else bhi[j] = mid;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SP_R / SP_T; ++j) {
+            const long long i = (long long)blockIdx.x * SP_R + j * SP_T + tid;
+            int bin = -1;
+            if (i < n_rows) bin = blo[j];
+            // most rows of a wave fall into one bin (the rows behind every queried pair)
+            const int b0 = __shfl(bin, 0, 64);
+            if (__all(bin == b0)) {
+                if (lane == 0 && b0 >= 0) atomicAdd(&hh[b0], 64u);
+            } else if (bin >= 0) {
+                atomicAdd(&hh[bin], 1u);
+            }
+        }
+        __syncthreads();
+#ifdef RAG_SP_TIMING
+        if (tid == 0 && blockIdx.x == 0) printf("rank phase: prep %.2f us, bin %.2f us\n", (t_prep - ts[2]) * 0.01, (wall_clock64() - t_prep) * 0.01);
+#endif
+        // (the last bin -- rows behind every queried pair, usually nearly all rows -- is never read)
+        unsigned long long* hrep = hist + (size_t)(blockIdx.x % SP_HREP) * (size_t)(nq + 1);
+        for (int i = tid; i < nq; i += SP_T)
+            if (hh[i]) atomicAdd(&hrep[i], (unsigned long long)hh[i]);
+    }
+
+    SP_STAMP();
+    // ---- d. the workgroup that finishes last does the rest.  Hand-off (Guideline 16, counter form): everything
+    // this workgroup published went out by write-through (sc1) stores or by agent-scope atomics, every wave
+    // drains its stores, then ONE lane draws the ticket behind the workgroup barrier; the last arriver
+    // acquires at agent scope before it reads.  (A release fence in each of ~1000 workgroups cost 12 us here.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        // two-level ticket: one word takes ~88 returning atomics per microsecond, a thousand workgroups on
+        // one word were 11 us; SP_TGRP words on cache lines of their own, then one
+        const int nb = (int)gridDim.x, g = (int)blockIdx.x % SP_TGRP;
+        const int gsize = (nb - g + SP_TGRP - 1) / SP_TGRP;
+        int last = 0;
+        const int t = __hip_atomic_fetch_add(&counters[SP_TICKET0 + g * 32], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gsize - 1) {
+            const int groups = nb < SP_TGRP ? nb : SP_TGRP;
+            const int t2 = __hip_atomic_fetch_add(&counters[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (t2 == groups - 1) ? 1 : 0;
+        }
+        misc[0] = last;
+    }
+    __syncthreads();
+    if (misc[0] == 0) return;
+    SP_STAMP();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    SP_STAMP();
+
+    // ---- e. the counters, the rank histogram and the first SP_SORT candidates in one round trip
+    const int cnt = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ceq = __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < nq; i += SP_T) {
+        unsigned long long a = 0;
+#pragma unroll 8
+        for (int r = 0; r < SP_HREP; ++r)
+            a += __hip_atomic_load(&hist[(size_t)r * (size_t)(nq + 1) + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hl[i] = a;
+    }
+    const bool small = cnt <= SP_SORT;
+    int M = 64;
+    if (small) {
+        while (M < cnt) M <<= 1;
+        for (int i = tid; i < M; i += SP_T) {
+            sk[i] = i < cnt ? buf_key[i] : -DBL_MAX;
+            si[i] = i < cnt ? buf_id[i] : INT_MAX;
+        }
+    }
+    __syncthreads();
+    if (nq > 0) {
+        for (int i = tid; i < nq; i += SP_T) {
+            unsigned long long run = 0;
+            const int pos = po[i];
+            for (int p = 0; p <= pos; ++p) run += hl[p];
+            if (out_rank) out_rank[i] = (long long)(run - 1ULL);
+            if (out_rowscore) out_rowscore[i] = uk[i];
+        }
+    }
+
+    SP_STAMP();
+    // ---- f. exact selection among the appended scores, ties completed by ascending row (select_fill_kernel)
+    if (cnt > THR_CAP) {  // uniform: the caller reruns the selection with the list kernels
+        if (tid == 0) *out_flag = 1;
+        return;
+    }
+    if (tid == 0) *out_flag = 0;
+    const int have = cnt < k ? cnt : k;
+    if (cnt <= SP_COUNT) {  // rank by counting: position = number of candidates ahead; `parts` threads per candidate
+        const int parts = M >= SP_T ? 1 : SP_T / M;
+        __syncthreads();
+        for (int i = tid; i < M; i += SP_T) ahead_of[i] = 0;
+        __syncthreads();
+        for (int w0 = 0; w0 < cnt; w0 += SP_T / parts) {
+            const int i = w0 + tid / parts, part = tid % parts;
+            if (i < cnt) {
+                const double kk = sk[i];
+                const int id = si[i];
+                int ahead = 0;
+                for (int j = part; j < cnt; j += parts) {
+                    const double ok = sk[j];
+                    const int oi = si[j];
+                    ahead += (ok > kk || (ok == kk && oi < id)) ? 1 : 0;
+                }
+                if (ahead) atomicAdd(&ahead_of[i], ahead);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < cnt; i += SP_T) {
+            const int ahead = ahead_of[i];
+            if (ahead < k) {  // staged: scattered 8-byte stores to host memory are one PCIe write each
+                mk[ahead] = sk[i];
+                stage_i[ahead] = si[i];
+            }
+        }
+        __syncthreads();
+#ifdef RAG_SP_TIMING
+        const unsigned long long t_cnt = wall_clock64();
+        if (tid == 0) printf("count loop %.2f us\n", (t_cnt - ts[6]) * 0.01);
+#endif
+        for (int p = tid; p < have; p += SP_T) {
+            out_D[p] = mk[p];
+            out_I[p] = (long long)stage_i[p];
+        }
+#ifdef RAG_SP_TIMING
+        SP_STAMP();
+        if (tid == 0)
+            printf("select k=%d G=%d nq=%d cnt=%d ceq=%d M=%d | us: thr %.2f compact %.2f rank %.2f ticket %.2f acquire %.2f loads+ranks %.2f count-select %.2f\n",
+                   k, G, nq, cnt, ceq, M, (ts[1] - ts[0]) * 0.01, (ts[2] - ts[1]) * 0.01, (ts[3] - ts[2]) * 0.01,
+                   (ts[4] - ts[3]) * 0.01, (ts[5] - ts[4]) * 0.01, (ts[6] - ts[5]) * 0.01, (ts[7] - ts[6]) * 0.01);
+#endif
+    } else if (small) {
+        lds_sort_pairs(sk, si, M, tid);
+#ifdef RAG_SP_TIMING
+        SP_STAMP();
+        if (tid == 0)
+            printf("select k=%d G=%d nq=%d cnt=%d ceq=%d M=%d | us: thr %.2f compact %.2f rank %.2f ticket %.2f acquire %.2f loads+ranks %.2f sort %.2f\n",
+                   k, G, nq, cnt, ceq, M, (ts[1] - ts[0]) * 0.01, (ts[2] - ts[1]) * 0.01, (ts[3] - ts[2]) * 0.01,
+                   (ts[4] - ts[3]) * 0.01, (ts[5] - ts[4]) * 0.01, (ts[6] - ts[5]) * 0.01, (ts[7] - ts[6]) * 0.01);
+#endif
+        for (int p = tid; p < have; p += SP_T) {
+            out_D[p] = sk[p];
+            out_I[p] = (long long)si[p];
+        }
+    } else {
+        WaveTopK<double, int, KS> tk;
+        block_merge<double, int, KS, SP_T / 64>(
+            [&](long long c, double& key, int& id) {
+                key = buf_key[c];
+                id = buf_id[c];
+                return true;
+            },
+            (long long)cnt, k, tk, mk, mi);
+        if (tid < 64) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s * 64 + lane;
+                if (p < have) {
+                    out_D[p] = tk.key[s];
+                    out_I[p] = (long long)tk.id[s];
+                }
+            }
+        }
+    }
+    if (have == k) return;
+    const int need = k - have;
+    if (ceq <= THR_CAP) {  // few rows score exactly T: all remembered; the lowest row numbers complete the list
+        __syncthreads();
+        if (ceq <= SP_SORT) {
+            int M2 = 64;
+            while (M2 < ceq) M2 <<= 1;
+            for (int i = tid; i < M2; i += SP_T) {
+                const int id = i < ceq ? eq_id[i] : INT_MAX;
+                sk[i] = i < ceq ? -(double)id : -DBL_MAX;
+                si[i] = id;
+            }
+            __syncthreads();
+            lds_sort_pairs(sk, si, M2, tid);
+            for (int p = tid; p < need && p < ceq; p += SP_T) {
+                out_D[have + p] = T;
+                out_I[have + p] = (long long)si[p];
+            }
+            return;
+        }
+        WaveTopK<double, int, KS> te;
+        block_merge<double, int, KS, SP_T / 64>(
+            [&](long long c, double& key, int& id) {
+                id = eq_id[c];
+                key = -(double)id;
+                return true;
+            },
+            (long long)ceq, need, te, mk, mi);
+        if (tid < 64) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s * 64 + lane;
+                if (p < need && p < ceq) {
+                    out_D[have + p] = T;
+                    out_I[have + p] = (long long)te.id[s];
+                }
+            }
+        }
+        return;
+    }
+    // many rows score exactly T (the zeros of a BM25 vector): the first k - have of them from row 0
+    if (tid == 0) misc[1] = have;
+    __syncthreads();
+    for (long long base = 0; base < n_rows; base += SP_T) {
+        const long long i = base + tid;
+        const bool eq = i < n_rows && score[i] == T;
+        const unsigned long long m = __ballot(eq);
+        if (lane == 0) misc[2 + wid] = __popcll(m);
+        __syncthreads();
+        int before = misc[1];
+        for (int w = 0; w < wid; ++w) before += misc[2 + w];
+        int total = 0;
+        for (int w = 0; w < SP_T / 64; ++w) total += misc[2 + w];
+        if (eq) {
+            const int pos = before + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < k) {
+                out_D[pos] = T;
+                out_I[pos] = i;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) misc[1] += total;
+        __syncthreads();
+        if (misc[1] >= k) break;
+    }
+}
+
 }  // namespace
 
 struct rag_csc {
@@ -454,6 +1050,14 @@ struct rag_csc {
     double* rk_gather = nullptr;  // rag_tfidf_query: scores of the queried rows
     long long* rk_rows = nullptr; unsigned long long* rk_out = nullptr;
     double* rk_skey = nullptr; long long* rk_srow = nullptr; int* rk_pos = nullptr; unsigned long long* rk_hist = nullptr;
+    // fused path: row blocks, skip table of the frequent terms, span maxima
+    bool fused = false;             // postings ascend strictly by row within every term and the skip table is built
+    int64_t nblk = 0;               // workgroups = ceil(n_rows / SP_R)
+    int64_t n_freq = 0;             // rows of the skip table
+    int* skip = nullptr;            // [n_freq][nblk + 1] posting offsets (relative to the term's first posting)
+    std::vector<int> ft_of_term;    // term -> row of the skip table, -1: rare
+    double* wmax = nullptr;         // [nblk * SP_SUB] maxima of the 64-row spans
+    double* bmax = nullptr;         // [nblk] maxima of the row blocks
     std::mutex mu;
 };
 
@@ -469,6 +1073,8 @@ int term_grid(long long len) {
     return (int)nb;
 }
 
+int ensure_topk_ws(rag_csc* h, long long nb, int k, bool thr_path);
+
 // Dense top-k of h->score into host D/I (k entries; pads when k > n_rows).
 int topk_scores(rag_csc* h, int k, double* D, int64_t* I, hipStream_t st) {
     if (k <= 0) return RAG_OK;
@@ -479,18 +1085,9 @@ int topk_scores(rag_csc* h, int k, double* D, int64_t* I, hipStream_t st) {
     // threshold path for large score vectors (see span_max_kernel); the list kernels stay enqueued
     // behind it and return at once unless its buffer overflowed
     const bool thr_path = h->n_rows >= 65536 && k <= SPANS / 4 && options().sparse_topk_lists == 0;
-    if (thr_path && h->thr_ws == nullptr) {
-        RAG_HIP(hipMalloc(&h->thr_ws, (size_t)(SPANS + 1) * sizeof(double)));
-        RAG_HIP(hipMalloc(&h->thr_cnt, 4 * sizeof(int)));
-    }
-    if (std::max<long long>(nb * k, thr_path ? 2 * THR_CAP : 0) > h->cand_cap) {
-        if (h->cand_key) RAG_HIP(hipFree(h->cand_key));
-        if (h->cand_id) RAG_HIP(hipFree(h->cand_id));
-        h->cand_key = nullptr; h->cand_id = nullptr; h->cand_cap = 0;
-        const int64_t want = std::max<int64_t>(nb * k, 2 * THR_CAP);
-        RAG_HIP(hipMalloc(&h->cand_key, (size_t)want * sizeof(double)));
-        RAG_HIP(hipMalloc(&h->cand_id, (size_t)want * sizeof(int)));
-        h->cand_cap = want;
+    {
+        const int rcw = ensure_topk_ws(h, nb, k, thr_path);
+        if (rcw) return rcw;
     }
     if (k > h->out_cap) {
         if (h->out_D) RAG_HIP(hipFree(h->out_D));
@@ -536,7 +1133,6 @@ int topk_scores(rag_csc* h, int k, double* D, int64_t* I, hipStream_t st) {
     RAG_HIP(hipGetLastError());
     // into pinned memory (true asynchronous copies); topk_finish() hands them over after the caller's
     // synchronisation
-    if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
     RAG_HIP(hipMemcpyAsync(h->pin, h->out_D, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, st));
     RAG_HIP(hipMemcpyAsync(h->pin + PIN_BYTES / 2, h->out_I, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, st));
     return RAG_OK;
@@ -546,6 +1142,156 @@ void topk_finish(rag_csc* h, int k, double* D, int64_t* I) {
     if (k <= 0) return;
     std::memcpy(D, h->pin, (size_t)k * sizeof(double));
     std::memcpy(I, h->pin + PIN_BYTES / 2, (size_t)k * sizeof(long long));
+}
+
+
+// Workspaces of the top-k (both paths).
+int ensure_topk_ws(rag_csc* h, long long nb, int k, bool thr_path) {
+    if (thr_path && h->thr_ws == nullptr) {
+        RAG_HIP(hipMalloc(&h->thr_ws, (size_t)(SPANS + 1) * sizeof(double)));
+        RAG_HIP(hipMalloc(&h->thr_cnt, SP_NCOUNTERS * sizeof(int)));
+        RAG_HIP(hipMemset(h->thr_cnt, 0, SP_NCOUNTERS * sizeof(int)));
+    }
+    if (std::max<long long>(nb * k, thr_path ? 2 * THR_CAP : 0) > h->cand_cap) {
+        if (h->cand_key) RAG_HIP(hipFree(h->cand_key));
+        if (h->cand_id) RAG_HIP(hipFree(h->cand_id));
+        h->cand_key = nullptr; h->cand_id = nullptr; h->cand_cap = 0;
+        const int64_t want = std::max<int64_t>(nb * k, 2 * THR_CAP);
+        RAG_HIP(hipMalloc(&h->cand_key, (size_t)want * sizeof(double)));
+        RAG_HIP(hipMalloc(&h->cand_id, (size_t)want * sizeof(int)));
+        h->cand_cap = want;
+    }
+    if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+    return RAG_OK;
+}
+
+// Fused scoring: one launch per SP_MAXT query terms (usually one).  weights: idf per TERM ID (BM25) or per
+// QUERY POSITION (TF-IDF).  n_qrow > 0: the rows of a rank query wait in pinned memory at PIN_Q_ROWS and are
+// brought to rk_rows by workgroup 0 of the (last) launch, which also clears the selection kernel's counters.
+int launch_fused_scores(rag_csc* h, bool bm25, int nt, const int32_t* tids, const double* qw, int n_qrow,
+                        int thr_G, int thr_k, hipStream_t st) {
+    if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+    if (h->thr_cnt == nullptr) {
+        RAG_HIP(hipMalloc(&h->thr_ws, (size_t)(SPANS + 1) * sizeof(double)));
+        RAG_HIP(hipMalloc(&h->thr_cnt, SP_NCOUNTERS * sizeof(int)));
+        RAG_HIP(hipMemset(h->thr_cnt, 0, SP_NCOUNTERS * sizeof(int)));
+    }
+    const double k1p1 = h->k1 + 1.0, omb = 1.0 - h->b;  // Python evaluates these once per term as float64 scalars
+    SpTerms qt;
+    int done = 0;
+    bool first = true;
+    do {
+        qt.n = 0;
+        while (done < nt && qt.n < SP_MAXT) {
+            const int t = tids[done];
+            const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
+            if (b1 > b0) {
+                qt.freq[qt.n] = h->ft_of_term[t];
+                qt.begin[qt.n] = b0;
+                qt.end[qt.n] = b1;
+                qt.w[qt.n] = bm25 ? h->idf[t] : qw[done];
+                ++qt.n;
+            }
+            ++done;
+        }
+        const bool last = done >= nt;
+        const int nqr = last ? n_qrow : 0;
+        const int tG = last ? thr_G : 0;   // the threshold comes from the final scores
+        const int per_block = h->nblk >= thr_G ? 1 : 0;
+        double* thr_out = h->thr_ws + SPANS;
+        const long long* qh = reinterpret_cast<const long long*>(h->pin + PIN_Q_ROWS);
+        if (bm25)
+            sparse_score_kernel<true><<<(unsigned)h->nblk, SP_T, 0, st>>>(
+                qt, h->row, h->val, h->skip, (long long)(h->nblk + 1), h->doc_len, h->avgdl, h->k1, h->b, k1p1, omb,
+                (long long)h->n_rows, h->score, h->wmax, h->bmax, first ? 0 : 1, h->thr_cnt, SP_ZERO_PER_CALL, h->rk_hist,
+                nqr ? SP_HREP * (nqr + 1) : 0, qh, h->rk_rows, nqr, tG, thr_k, per_block, thr_out);
+        else
+            sparse_score_kernel<false><<<(unsigned)h->nblk, SP_T, 0, st>>>(
+                qt, h->row, h->val, h->skip, (long long)(h->nblk + 1), nullptr, 0.0, 0.0, 0.0, 0.0, 0.0,
+                (long long)h->n_rows, h->score, h->wmax, h->bmax, first ? 0 : 1, h->thr_cnt, SP_ZERO_PER_CALL, h->rk_hist,
+                nqr ? SP_HREP * (nqr + 1) : 0, qh, h->rk_rows, nqr, tG, thr_k, per_block, thr_out);
+        RAG_HIP(hipGetLastError());
+        first = false;
+    } while (done < nt);
+    h->have_scores = true;
+    return RAG_OK;
+}
+
+// Can the fused selection kernel serve (k, n_rows)?  It needs k <= the number of real span groups (else its
+// threshold is -DBL_MAX and every row is a candidate, which only a small vector survives).
+bool fused_select_ok(const rag_csc* h, int k, int* G_out) {
+    if (!h->fused || k < 1 || k > RAG_MAX_K || k > h->n_rows || options().sparse_topk_lists != 0) return false;
+    // T = the k-th largest of ng group maxima; for scores in no particular order about -ng*ln(1 - k/ng) rows
+    // exceed it (82 for k = 70, ng = 256; 960 for k = 250): 256 groups serve k <= 200, 1024 the rest
+    const int G = k <= 200 ? 256 : 1024;
+    const long long n_g = h->nblk >= G ? h->nblk : h->nblk * SP_SUB;  // maxima per workgroup, or per 64-row span
+    const long long gs = (n_g + G - 1) / G;
+    const long long ng = (n_g + gs - 1) / gs;
+    *G_out = G;
+    return 4 * ng >= 5LL * k || h->n_rows <= THR_CAP;
+}
+
+// Selection (+ rank query) behind launch_fused_scores on the same stream; results land in pinned memory.
+int launch_fused_select(rag_csc* h, int k, int G, int n_qrow, bool want_ranks, bool want_scores, hipStream_t st) {
+    const int KS = ks_for(k);
+    int rc = ensure_topk_ws(h, 1, k, true);
+    if (rc) return rc;
+    (void)G;
+    const size_t smem = sp_select_smem(0, n_qrow, KS);
+    double* oD = reinterpret_cast<double*>(h->pin);
+    long long* oI = reinterpret_cast<long long*>(h->pin + PIN_BYTES / 2);
+    long long* oR = want_ranks ? reinterpret_cast<long long*>(h->pin + PIN_Q_RANKS) : nullptr;
+    double* oS = want_scores ? reinterpret_cast<double*>(h->pin + PIN_Q_SCORES) : nullptr;
+    int* oF = reinterpret_cast<int*>(h->pin + PIN_FLAG);
+    int* eq_id = h->cand_id + THR_CAP;
+#define RAG_SP_SELECT(KSV)                                                                                          \
+    do {                                                                                                            \
+        auto fn = sparse_select_kernel<KSV>;                                                                        \
+        if (smem > 48 * 1024)                                                                                       \
+            RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)smem));                                                                \
+        fn<<<(unsigned)h->nblk, SP_T, smem, st>>>(h->score, (long long)h->n_rows, h->thr_ws + SPANS, 0, k, h->cand_key, \
+                                                  h->cand_id, eq_id,                                                 \
+                                                  h->thr_cnt, n_qrow, h->rk_rows, h->rk_hist, oD, oI, oR, oS, oF);   \
+    } while (0)
+    if (KS == 1) RAG_SP_SELECT(1);
+    else if (KS == 2) RAG_SP_SELECT(2);
+    else RAG_SP_SELECT(4);
+#undef RAG_SP_SELECT
+    RAG_HIP(hipGetLastError());
+    return RAG_OK;
+}
+
+// Skip table + row blocks of the fused path (host side of rag_csc_create).  false: the postings of some
+// term do not ascend strictly by row, or the table would be unreasonably large -> per-term kernels.
+bool build_fused_index(rag_csc* h, const int64_t* indptr, const int32_t* row, std::vector<int>* skip_host) {
+    if (h->n_rows <= 0 || h->n_terms <= 0) return false;
+    for (int64_t t = 0; t < h->n_terms; ++t)
+        for (int64_t p = indptr[t] + 1; p < indptr[t + 1]; ++p)
+            if (row[p] <= row[p - 1]) return false;
+    h->nblk = (h->n_rows + SP_R - 1) / SP_R;
+    h->ft_of_term.assign((size_t)h->n_terms, -1);
+    int64_t nf = 0;
+    for (int64_t t = 0; t < h->n_terms; ++t)
+        if (indptr[t + 1] - indptr[t] >= SP_FREQ_MIN) h->ft_of_term[(size_t)t] = (int)nf++;
+    if ((double)nf * (double)(h->nblk + 1) * 4.0 > 4e9) return false;  // > 4 GB of skip table
+    h->n_freq = nf;
+    skip_host->assign((size_t)nf * (size_t)(h->nblk + 1), 0);
+    for (int64_t t = 0; t < h->n_terms; ++t) {
+        const int f = h->ft_of_term[(size_t)t];
+        if (f < 0) continue;
+        const int32_t* r0 = row + indptr[t];
+        const int64_t df = indptr[t + 1] - indptr[t];
+        int* sk = skip_host->data() + (size_t)f * (size_t)(h->nblk + 1);
+        int64_t p = 0;
+        for (int64_t b = 0; b <= h->nblk; ++b) {  // first posting with row >= b * SP_R (one forward walk)
+            const int64_t bound = b * SP_R;
+            if (b == h->nblk) p = df;
+            else if (p < df && r0[p] < bound) p = std::lower_bound(r0 + p, r0 + df, (int32_t)std::min<int64_t>(bound, INT_MAX)) - r0;
+            sk[b] = (int)p;
+        }
+    }
+    return true;
 }
 
 }  // namespace
@@ -580,13 +1326,24 @@ int rag_csc_create(int64_t n_terms, int64_t n_rows, const int64_t* indptr, const
         if (e == hipSuccess) e = hipMemcpy(h->row, row, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(h->val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
     }
+    {
+        std::vector<int> skip_host;
+        if (nnz > 0 && build_fused_index(h, indptr, row, &skip_host)) {
+            if (e == hipSuccess) e = hipMalloc(&h->skip, std::max<size_t>(skip_host.size(), 1) * sizeof(int));
+            if (e == hipSuccess && !skip_host.empty())
+                e = hipMemcpy(h->skip, skip_host.data(), skip_host.size() * sizeof(int), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc(&h->wmax, (size_t)h->nblk * SP_SUB * sizeof(double));
+            if (e == hipSuccess) e = hipMalloc(&h->bmax, (size_t)h->nblk * sizeof(double));
+            h->fused = e == hipSuccess;
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(&h->score, (size_t)std::max<int64_t>(n_rows, 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->rk_rows, RANK_MAXQ * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->rk_out, RANK_MAXQ * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&h->rk_skey, RANK_MAXQ * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->rk_srow, RANK_MAXQ * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->rk_pos, RANK_MAXQ * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&h->rk_hist, (RANK_MAXQ + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->rk_hist, (size_t)SP_HREP * (RANK_MAXQ + 1) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         rag_csc_free(h);
         return fail(e == hipErrorOutOfMemory ? RAG_ERR_OOM : RAG_ERR_HIP, "rag_csc_create: %s", hipGetErrorString(e));
@@ -616,6 +1373,9 @@ void rag_csc_free(rag_csc_t* h) {
     (void)hipFree(h->rk_pos);
     (void)hipFree(h->rk_hist);
     (void)hipFree(h->rk_gather);
+    (void)hipFree(h->skip);
+    (void)hipFree(h->wmax);
+    (void)hipFree(h->bmax);
     delete h;
 }
 
@@ -634,6 +1394,54 @@ int rag_bm25_set(rag_csc_t* h, const double* idf, const int32_t* doc_len, double
     return RAG_OK;
 }
 
+// Per-term launches (postings not sorted by row, or no skip table): scores accumulate in HBM.
+static int launch_term_scores(rag_csc* h, bool bm25, int nt, const int32_t* tids, const double* qw, hipStream_t st) {
+    if (h->n_rows > 0) RAG_HIP(hipMemsetAsync(h->score, 0, (size_t)h->n_rows * sizeof(double), st));
+    // Python evaluates (self.k1 + 1) and (1 - self.b) once per term as float64 scalars.
+    const double k1p1 = h->k1 + 1.0, omb = 1.0 - h->b;
+    for (int i = 0; i < nt; ++i) {
+        const int t = tids[i];
+        const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
+        if (b1 <= b0) continue;
+        if (bm25)
+            bm25_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, h->idf[t], h->doc_len, h->avgdl,
+                                                                h->k1, h->b, k1p1, omb, h->score);
+        else
+            tfidf_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, qw[i], h->score);
+    }
+    RAG_HIP(hipGetLastError());
+    h->have_scores = true;
+    return RAG_OK;
+}
+
+// Scores (+ optional copy of the whole vector to the host) + top-k, one synchronisation.
+static int score_and_topk(rag_csc* h, bool bm25, int nt, const int32_t* tids, const double* qw, double* scores_or_null,
+                          int k, double* D, int64_t* I) {
+    hipStream_t st = lib_stream();
+    const bool fused = h->fused && options().sparse_fused != 0;
+    int G = 0;
+    const bool fsel = fused && k > 0 && fused_select_ok(h, k, &G);
+    int rc = fused ? launch_fused_scores(h, bm25, nt, tids, qw, 0, fsel ? G : 0, k, st)
+                   : launch_term_scores(h, bm25, nt, tids, qw, st);
+    if (rc) return rc;
+    if (scores_or_null && h->n_rows > 0)
+        RAG_HIP(hipMemcpyAsync(scores_or_null, h->score, (size_t)h->n_rows * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (fsel) {
+        rc = launch_fused_select(h, k, G, 0, false, false, st);
+        if (rc) return rc;
+        RAG_HIP(hipStreamSynchronize(st));
+        if (*reinterpret_cast<volatile int*>(h->pin + PIN_FLAG) == 0) {
+            topk_finish(h, k, D, I);
+            return RAG_OK;
+        }  // buffer overflow (scores sorted by row number, say): the list kernels take over
+    }
+    rc = topk_scores(h, k, D, I, st);
+    if (rc) return rc;
+    RAG_HIP(hipStreamSynchronize(st));
+    topk_finish(h, k, D, I);
+    return RAG_OK;
+}
+
 int rag_bm25_scores(rag_csc_t* h, int n_qterms, const int32_t* term_ids, double* scores_or_null, int k, double* D,
                     int64_t* I) {
     RAG_REQUIRE_INIT();
@@ -644,26 +1452,7 @@ int rag_bm25_scores(rag_csc_t* h, int n_qterms, const int32_t* term_ids, double*
     for (int i = 0; i < n_qterms; ++i)
         if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
             return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
-    hipStream_t st = lib_stream();
-    if (h->n_rows > 0) RAG_HIP(hipMemsetAsync(h->score, 0, (size_t)h->n_rows * sizeof(double), st));
-    // Python evaluates (self.k1 + 1) and (1 - self.b) once per term as float64 scalars.
-    const double k1p1 = h->k1 + 1.0, omb = 1.0 - h->b;
-    for (int i = 0; i < n_qterms; ++i) {
-        const int t = term_ids[i];
-        const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
-        if (b1 <= b0) continue;
-        bm25_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, h->idf[t], h->doc_len, h->avgdl,
-                                                            h->k1, h->b, k1p1, omb, h->score);
-    }
-    RAG_HIP(hipGetLastError());
-    h->have_scores = true;
-    if (scores_or_null && h->n_rows > 0)
-        RAG_HIP(hipMemcpyAsync(scores_or_null, h->score, (size_t)h->n_rows * sizeof(double), hipMemcpyDeviceToHost, st));
-    int rc = topk_scores(h, k, D, I, st);
-    if (rc) return rc;
-    RAG_HIP(hipStreamSynchronize(st));
-    topk_finish(h, k, D, I);
-    return RAG_OK;
+    return score_and_topk(h, true, n_qterms, term_ids, nullptr, scores_or_null, k, D, I);
 }
 
 int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights,
@@ -675,23 +1464,7 @@ int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const dou
     for (int i = 0; i < nnz_q; ++i)
         if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
             return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
-    hipStream_t st = lib_stream();
-    if (h->n_rows > 0) RAG_HIP(hipMemsetAsync(h->score, 0, (size_t)h->n_rows * sizeof(double), st));
-    for (int i = 0; i < nnz_q; ++i) {
-        const int t = term_ids[i];
-        const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
-        if (b1 <= b0) continue;
-        tfidf_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, q_weights[i], h->score);
-    }
-    RAG_HIP(hipGetLastError());
-    h->have_scores = true;
-    if (scores_or_null && h->n_rows > 0)
-        RAG_HIP(hipMemcpyAsync(scores_or_null, h->score, (size_t)h->n_rows * sizeof(double), hipMemcpyDeviceToHost, st));
-    int rc = topk_scores(h, k, D, I, st);
-    if (rc) return rc;
-    RAG_HIP(hipStreamSynchronize(st));
-    topk_finish(h, k, D, I);
-    return RAG_OK;
+    return score_and_topk(h, false, nnz_q, term_ids, q_weights, scores_or_null, k, D, I);
 }
 
 int rag_tfidf_query(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights, int k, double* D,
@@ -711,23 +1484,46 @@ int rag_tfidf_query(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const doub
         if (rows[i] < 0 || rows[i] >= h->n_rows)
             return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)rows[i], (long long)h->n_rows);
     hipStream_t st = lib_stream();
-    if (h->n_rows > 0) RAG_HIP(hipMemsetAsync(h->score, 0, (size_t)h->n_rows * sizeof(double), st));
-    for (int i = 0; i < nnz_q; ++i) {
-        const int t = term_ids[i];
-        const long long b0 = h->indptr[t], b1 = h->indptr[t + 1];
-        if (b1 <= b0) continue;
-        tfidf_term_kernel<<<term_grid(b1 - b0), 256, 0, st>>>(h->row, h->val, b0, b1, q_weights[i], h->score);
-    }
-    RAG_HIP(hipGetLastError());
-    h->have_scores = true;
-    int rc = topk_scores(h, k, D, I, st);
-    if (rc) return rc;
     const bool want_ranks = n_query > 0 && ranks != nullptr, want_scores = n_query > 0 && row_scores != nullptr;
-    if (want_ranks || want_scores) {
-        if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
-        std::memcpy(h->pin + PIN_Q_ROWS, rows, (size_t)n_query * sizeof(long long));
-        RAG_HIP(hipMemcpyAsync(h->rk_rows, h->pin + PIN_Q_ROWS, (size_t)n_query * sizeof(long long), hipMemcpyHostToDevice, st));
+    const int nqr = (want_ranks || want_scores) ? n_query : 0;
+    if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+    if (nqr) std::memcpy(h->pin + PIN_Q_ROWS, rows, (size_t)n_query * sizeof(long long));
+    const bool fused = h->fused && options().sparse_fused != 0;
+    int G = 0;
+    const bool fsel = fused && k > 0 && fused_select_ok(h, k, &G);
+    // fused: scores, then selection + rank query in one more launch; the rows travel with the first launch
+    int rc = fused ? launch_fused_scores(h, false, nnz_q, term_ids, q_weights, fsel ? nqr : 0, fsel ? G : 0, k, st)
+                   : launch_term_scores(h, false, nnz_q, term_ids, q_weights, st);
+    if (rc) return rc;
+    if (fsel) {
+        rc = launch_fused_select(h, k, G, nqr, want_ranks, want_scores, st);
+        if (rc) return rc;
+        RAG_HIP(hipStreamSynchronize(st));
+        if (*reinterpret_cast<volatile int*>(h->pin + PIN_FLAG) != 0) {  // selection buffer overflow: list kernels
+            // (the rank query's results are already in pinned memory: save them from the top-k's staging area)
+            std::vector<long long> rsave;
+            std::vector<double> ssave;
+            if (want_ranks) rsave.assign(reinterpret_cast<long long*>(h->pin + PIN_Q_RANKS),
+                                         reinterpret_cast<long long*>(h->pin + PIN_Q_RANKS) + n_query);
+            if (want_scores) ssave.assign(reinterpret_cast<double*>(h->pin + PIN_Q_SCORES),
+                                          reinterpret_cast<double*>(h->pin + PIN_Q_SCORES) + n_query);
+            rc = topk_scores(h, k, D, I, st);
+            if (rc) return rc;
+            RAG_HIP(hipStreamSynchronize(st));
+            topk_finish(h, k, D, I);
+            if (want_ranks) std::memcpy(ranks, rsave.data(), (size_t)n_query * sizeof(long long));
+            if (want_scores) std::memcpy(row_scores, ssave.data(), (size_t)n_query * sizeof(double));
+            return RAG_OK;
+        }
+        topk_finish(h, k, D, I);
+        if (want_ranks) std::memcpy(ranks, h->pin + PIN_Q_RANKS, (size_t)n_query * sizeof(long long));
+        if (want_scores) std::memcpy(row_scores, h->pin + PIN_Q_SCORES, (size_t)n_query * sizeof(double));
+        return RAG_OK;
     }
+    rc = topk_scores(h, k, D, I, st);
+    if (rc) return rc;
+    if (want_ranks || want_scores)
+        RAG_HIP(hipMemcpyAsync(h->rk_rows, h->pin + PIN_Q_ROWS, (size_t)n_query * sizeof(long long), hipMemcpyHostToDevice, st));
     if (want_ranks) {
         long long nb = (h->n_rows + 2047) / 2048;
         nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));

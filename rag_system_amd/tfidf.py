@@ -13,6 +13,8 @@ here M is re-normalised ONCE at upload (sklearn.preprocessing.normalize, the sam
 cosine_similarity calls), stored term-major in HBM, and each query runs rag_tfidf_scores
 (csrc/sparse.hip), which adds w_t * M[doc, t] term by term in scipy's order.
 """
+import math
+
 import numpy as np
 
 from . import bm25 as _bm25
@@ -29,32 +31,40 @@ class TfidfScorer:
         self._csc = _bm25.make_csc(self.n_terms, self.n_docs, csc.indptr.astype(np.int64),
                                    csc.indices.astype(np.int32), csc.data.astype(np.float64))
 
+    @staticmethod
+    def _normalize_row(indices, data):
+        """What cosine_similarity does to a one-row X -- sklearn.preprocessing.normalize(X) (l2:
+        inplace_csr_row_normalize_l2 sums the squares of the stored values one after another, takes
+        the square root and divides each value by it; an all-zero row stays as it is) followed by
+        sort_indices() -- restated in a few float operations, because building a scipy matrix and
+        calling sklearn per query costs more than the GPU side of the whole query (~0.15 ms against
+        ~0.03 ms).  Bit-identical to the sklearn route (tests/test_host_logic.py, test_sparse_gpu.py)."""
+        indices = np.asarray(indices, dtype=np.int32)
+        data = np.asarray(data, dtype=np.float64)
+        ssq = 0.0
+        for x in data.tolist():
+            ssq += x * x
+        if ssq != 0.0:
+            data = data / math.sqrt(ssq)
+        order = np.argsort(indices, kind="stable")
+        return np.ascontiguousarray(indices[order]), np.ascontiguousarray(data[order])
+
     def _normalized(self, qv):
-        from sklearn.preprocessing import normalize
-        qn = normalize(qv, copy=True)               # what cosine_similarity does to X
-        qn.sort_indices()
-        return qn.indices.astype(np.int32), qn.data.astype(np.float64)
+        qv = qv.tocsr()
+        return self._normalize_row(qv.indices, qv.data)
 
     def _query(self, query):
         return self._normalized(self.vectorizer.transform([query]))
 
     def scores_from_row(self, indices, data):
         """Scores for an already vectorised query row (the output of vectorizer.transform)."""
-        from scipy.sparse import csr_matrix
-        indices = np.asarray(indices, dtype=np.int32)
-        qv = csr_matrix((np.asarray(data, dtype=np.float64), indices, np.array([0, len(indices)], dtype=np.int32)),
-                        shape=(1, self.n_terms))
-        t, w = self._normalized(qv)
+        t, w = self._normalize_row(indices, data)
         s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
         return s
 
     def top_k_from_row(self, indices, data, k):
         """top_k() for an already vectorised query row (k <= MAX_FUSED_K)."""
-        from scipy.sparse import csr_matrix
-        indices = np.asarray(indices, dtype=np.int32)
-        qv = csr_matrix((np.asarray(data, dtype=np.float64), indices, np.array([0, len(indices)], dtype=np.int32)),
-                        shape=(1, self.n_terms))
-        t, w = self._normalized(qv)
+        t, w = self._normalize_row(indices, data)
         _, D, I = self._csc.tfidf_scores(t, w, want_scores=False, k=min(int(k), self.n_docs))
         return I, D
 
@@ -87,11 +97,7 @@ class TfidfScorer:
 
     def ranks_from_row(self, indices, data, k, doc_indices):
         """(top_idx, top_scores, ranks): top_k_from_row(k) + ranks(doc_indices) in one engine call."""
-        from scipy.sparse import csr_matrix
-        indices = np.asarray(indices, dtype=np.int32)
-        qv = csr_matrix((np.asarray(data, dtype=np.float64), indices, np.array([0, len(indices)], dtype=np.int32)),
-                        shape=(1, self.n_terms))
-        t, w = self._normalized(qv)
+        t, w = self._normalize_row(indices, data)
         D, I, ranks, _ = self._csc.tfidf_query(t, w, min(int(k), self.n_docs), doc_indices, want_scores=False)
         return I, D, ranks
 

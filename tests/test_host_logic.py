@@ -254,3 +254,23 @@ def test_quirks_gpu(engine):
 @pytest.mark.gpu
 def test_mmr_and_cross_encoder_gpu(engine):
     _run_mmr_and_cross_encoder()
+
+
+def test_query_row_normalisation_is_bit_identical_to_sklearn():
+    """TfidfScorer._normalize_row restates sklearn.preprocessing.normalize + sort_indices for one row
+    (what cosine_similarity does to the query, search_engine.py:285,331)."""
+    from scipy.sparse import csr_matrix
+    from sklearn.preprocessing import normalize
+    from rag_system_amd.tfidf import TfidfScorer
+    rng = np.random.default_rng(11)
+    V = 5000
+    for trial in range(300):
+        n = int(rng.integers(0, 40))
+        idx = rng.choice(V, n, replace=False).astype(np.int32)          # unsorted, as a caller may pass them
+        dat = rng.random(n) * rng.choice([1e-6, 1.0, 1e6]) if trial % 7 else np.zeros(n)
+        qv = csr_matrix((dat.astype(np.float64), idx, np.array([0, n], dtype=np.int32)), shape=(1, V))
+        qn = normalize(qv, copy=True)
+        qn.sort_indices()
+        t, w = TfidfScorer._normalize_row(idx, dat)
+        assert t.tolist() == qn.indices.tolist()
+        assert w.tobytes() == qn.data.astype(np.float64).tobytes()
