@@ -413,7 +413,7 @@ def c5_leg(n_queries=40):
         wl.query(qi)
     tsum = {s: 0.0 for s in STAGES}
     sb = {"bm25": 0.0, "tfidf": 0.0}
-    results = [wl.query(qi, tsum, sb) for qi in range(n_queries)]
+    results = [wl.query(qi, tsum, sb, keep_emb=qi < 3) for qi in range(n_queries)]
     checked = wl.check([0, 1, 2], results[:3])
     nq = float(n_queries)
     return {"workload": "strategy=rrf + MMR, 1M docs, vocab 200k, %d postings, dense 1M x 384 fp32, top_k=10" % wl.nnz,

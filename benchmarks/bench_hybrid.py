@@ -74,7 +74,7 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     for qi in range(args.queries):
-        results.append(wl.query(qi, tsum, sparse_bytes))
+        results.append(wl.query(qi, tsum, sparse_bytes, keep_emb=qi < 8))
     if prof is not None:
         import io
         import pstats

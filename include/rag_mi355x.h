@@ -228,6 +228,13 @@ int rag_rrf(int n_rankings, const int64_t* ids, const int64_t* lens, double k_co
 int rag_mmr(int C, int d, const float* cand, const float* q, double lambda, int top_k,
             const int64_t* byte_len, int64_t max_bytes, int32_t* out_order, int* out_n);
 
+/* mmr_selection with the candidates' embeddings taken from the flat index itself: candidate i is row
+ * rows[i] of `h` (a chunk the index holds) instead of a re-encoding of its text by the embedding model
+ * (search_engine.py:418 calls model.encode on every candidate).  Same selection rule and outputs as
+ * rag_mmr; identical results whenever the stored rows equal the re-encodings. */
+int rag_flat_mmr(rag_flat_t* h, int C, const int64_t* rows, const float* q, double lambda, int top_k,
+                 const int64_t* byte_len, int64_t max_bytes, int32_t* out_order, int* out_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,7 @@ SIGNATURES = {
     "rag_tfidf_query": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, _p, _p, C.c_int, _p, _p, _p]),
     "rag_rrf": (C.c_int, [C.c_int, _p, _p, C.c_double, _p, _p, _p]),
     "rag_mmr": (C.c_int, [C.c_int, C.c_int, _p, _p, C.c_double, C.c_int, _p, _i64, _p, _p]),
+    "rag_flat_mmr": (C.c_int, [_p, C.c_int, _p, _p, C.c_double, C.c_int, _p, _i64, _p, _p]),
 }
 
 _lock = threading.Lock()

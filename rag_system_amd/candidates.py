@@ -37,15 +37,31 @@ def _hip_mmr(cand, q, lam, top_k, byte_len, max_bytes):
     return order[:n_out.value].tolist()
 
 
+def _hip_mmr_stored(index_backend, rows, q, lam, top_k, byte_len, max_bytes):
+    lib = _lib.engine()
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+    byte_len = np.ascontiguousarray(byte_len, dtype=np.int64)
+    n = len(rows)
+    order = np.empty(max(n, 1), dtype=np.int32)
+    n_out = C.c_int()
+    _lib.check(lib.rag_flat_mmr(index_backend._h, n, _lib.ptr(rows), _lib.ptr(q), float(lam), int(top_k),
+                                _lib.ptr(byte_len), -1 if max_bytes is None else int(max_bytes), _lib.ptr(order),
+                                C.byref(n_out)), lib)
+    return order[:n_out.value].tolist()
+
+
 _rrf_impl = _hip_rrf
 _mmr_impl = _hip_mmr
+_mmr_stored_impl = _hip_mmr_stored
 
 
-def set_impl(rrf=None, mmr=None):
+def set_impl(rrf=None, mmr=None, mmr_stored=None):
     """Test seam for host-logic tests; None restores the HIP engine."""
-    global _rrf_impl, _mmr_impl
+    global _rrf_impl, _mmr_impl, _mmr_stored_impl
     _rrf_impl = rrf or _hip_rrf
     _mmr_impl = mmr or _hip_mmr
+    _mmr_stored_impl = mmr_stored or _hip_mmr_stored
 
 
 def reciprocal_rank_fusion(rankings, k=60):
@@ -73,3 +89,15 @@ def mmr_select(cand_emb, query_vec, byte_lens, lambda_param=0.5, top_k=None, max
         return []
     top_k = cand_emb.shape[0] if top_k is None else top_k
     return _mmr_impl(cand_emb, query_vec, lambda_param, top_k, byte_lens, max_context_bytes)
+
+
+def mmr_select_stored(index, rows, query_vec, byte_lens, lambda_param=0.5, top_k=None, max_context_bytes=None):
+    """mmr_select with the candidates' embeddings taken from the flat index itself (rag_flat_mmr):
+    candidate i is row rows[i] of `index` (a faiss_compat.IndexFlat on the HIP engine).  No
+    re-encoding, no upload of embeddings."""
+    rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+    if len(rows) == 0:
+        return []
+    backend = getattr(index, "_b", index)
+    top_k = len(rows) if top_k is None else top_k
+    return _mmr_stored_impl(backend, rows, query_vec, lambda_param, top_k, byte_lens, max_context_bytes)

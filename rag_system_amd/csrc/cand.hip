@@ -25,13 +25,35 @@ constexpr int MMR_MAX_C = 2048;
 // ids: all rankings concatenated (entry e belongs to ranking r with rank e - start[r]).
 // first[e] = smallest e' <= e with the same id.  An id's score is accumulated by the thread
 // owning its first entry, over its entries in order (= the order Python adds them).
-__global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __restrict__ ids,
-                                                           const int* __restrict__ rank_of, int T, double k_const,
+// Up to RRF_LDS_T entries (every call the search engine makes: three rankings of <= 9*top_k entries) the
+// ids, ranks and first-occurrence table live in LDS: the O(T^2) comparisons never leave the CU, and the
+// inputs may then sit in pinned HOST memory -- they are read exactly once, coalesced -- so that a call
+// is one launch and one synchronisation with no copies.  Larger T: the same code on the HBM copies.
+constexpr int RRF_LDS_T = 2048;
+template <bool LDS>
+__global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __restrict__ ids_g,
+                                                           const int* __restrict__ rank_g, int T, double k_const,
                                                            long long* __restrict__ out_ids,
                                                            double* __restrict__ out_scores, int* __restrict__ n_out,
-                                                           int* __restrict__ first) {
+                                                           int* __restrict__ first_g) {
     __shared__ int s_count[CAND_THREADS];
+    __shared__ long long s_ids[LDS ? RRF_LDS_T : 1];
+    __shared__ int s_rank[LDS ? RRF_LDS_T : 1];
+    __shared__ int s_first[LDS ? RRF_LDS_T : 1];
     const int tid = threadIdx.x;
+    const long long* ids = ids_g;
+    const int* rank_of = rank_g;
+    int* first = first_g;
+    if (LDS) {
+        for (int e = tid; e < T; e += CAND_THREADS) {
+            s_ids[e] = ids_g[e];
+            s_rank[e] = rank_g[e];
+        }
+        __syncthreads();
+        ids = s_ids;
+        rank_of = s_rank;
+        first = s_first;
+    }
     for (int e = tid; e < T; e += CAND_THREADS) {
         const long long id = ids[e];
         int f = e;
@@ -75,12 +97,22 @@ __global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __re
 
 // MMR.  cand: C x d (un-normalised fp32), q: d.  Work arrays in HBM: nrm (C x d normalised),
 // G (C x C cosine), simq (C).  One workgroup; selection order written to out_order.
+// STORED: candidate i is row rows[i] of a flat index' arena (fp32 or bfloat16 rows of `ld` elements) instead of
+// row i of `cand` -- the embeddings the index already holds, with no re-encoding and no upload.
+template <bool STORED>
 __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restrict__ cand, const float* __restrict__ q,
                                                            int C, int d, double lambda, int top_k,
                                                            const long long* __restrict__ byte_len, long long max_bytes,
                                                            float* __restrict__ nrm, float* __restrict__ G,
                                                            float* __restrict__ simq, int* __restrict__ out_order,
-                                                           int* __restrict__ out_n) {
+                                                           int* __restrict__ out_n, const long long* __restrict__ rows,
+                                                           const void* __restrict__ arena, int ld, int bf16) {
+    auto cval = [&](int i, int c) -> float {
+        if (!STORED) return cand[(size_t)i * d + c];
+        const size_t o = (size_t)rows[i] * ld + c;
+        if (bf16) return __uint_as_float((unsigned int)reinterpret_cast<const unsigned short*>(arena)[o] << 16);
+        return reinterpret_cast<const float*>(arena)[o];
+    };
     __shared__ float s_inv[MMR_MAX_C];     // 1/||cand_i|| (fp32, zero norm -> 1e-9 as :422)
     __shared__ float s_maxsim[MMR_MAX_C];  // max cosine to the selected set
     __shared__ unsigned char s_state[MMR_MAX_C];  // 0 = candidate, 1 = selected/removed
@@ -88,14 +120,18 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
     __shared__ int s_besti[CAND_THREADS / 64];
     __shared__ float s_qinv;
     __shared__ int s_pick;
+    __shared__ long long s_bytes[MMR_MAX_C];  // read once: the inputs may sit in pinned host memory
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = CAND_THREADS / 64;
+    for (int i = tid; i < C; i += CAND_THREADS) s_bytes[i] = byte_len[i];
 
     // row norms (one wave per row), query norm
     for (int i = wid; i <= C; i += NW) {
-        const float* v = i < C ? cand + (size_t)i * d : q;
         float ss = 0.f;
-        for (int c = lane; c < d; c += 64) ss = fmaf(v[c], v[c], ss);
+        for (int c = lane; c < d; c += 64) {
+            const float x = i < C ? cval(i, c) : q[c];
+            ss = fmaf(x, x, ss);
+        }
         for (int dist = 32; dist >= 1; dist >>= 1) ss += __shfl_xor(ss, dist);
         float n = sqrtf(ss);
         if (i < C) {
@@ -106,7 +142,7 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (size_t e = tid; e < (size_t)C * d; e += CAND_THREADS) nrm[e] = cand[e] / s_inv[e / d];
+    for (size_t e = tid; e < (size_t)C * d; e += CAND_THREADS) nrm[e] = cval((int)(e / d), (int)(e % d)) / s_inv[e / d];
     __syncthreads();
     // cosine to the query and the Gram matrix (one wave per dot product)
     for (int i = wid; i < C; i += NW) {
@@ -197,9 +233,9 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
         last = -1;
         // byte budget (search_engine.py:457-463): the first pick is never checked (:437)
         bool take = true;
-        if (!first_pick && max_bytes >= 0 && total_bytes + byte_len[pick] > max_bytes) take = false;
+        if (!first_pick && max_bytes >= 0 && total_bytes + s_bytes[pick] > max_bytes) take = false;
         if (take) {
-            total_bytes += byte_len[pick];
+            total_bytes += s_bytes[pick];
             if (tid == 0) out_order[n_sel] = pick;
             ++n_sel;
             last = pick;
@@ -288,18 +324,84 @@ int rag_rrf(int n_rankings, const int64_t* ids, const int64_t* lens, double k_co
     char* din = ws.dev;
     char* dout = ws.dev + in_b;
     char* dfirst = dout + out_b;
-    RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
-    rrf_kernel<<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<long long*>(din), reinterpret_cast<int*>(din + ids_b), (int)T,
-                                          k_const, reinterpret_cast<long long*>(dout + 8),
-                                          reinterpret_cast<double*>(dout + 8 + ids_b), reinterpret_cast<int*>(dout),
-                                          reinterpret_cast<int*>(dfirst));
-    RAG_HIP(hipGetLastError());
-    RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
+    if (T <= RRF_LDS_T) {
+        // the kernel reads the pinned inputs once into LDS and writes the results to pinned memory: no copies
+        rrf_kernel<true><<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<long long*>(hin), reinterpret_cast<int*>(hin + ids_b),
+                                                    (int)T, k_const, reinterpret_cast<long long*>(hout + 8),
+                                                    reinterpret_cast<double*>(hout + 8 + ids_b),
+                                                    reinterpret_cast<int*>(hout), nullptr);
+        RAG_HIP(hipGetLastError());
+    } else {
+        RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
+        rrf_kernel<false><<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<long long*>(din), reinterpret_cast<int*>(din + ids_b),
+                                                     (int)T, k_const, reinterpret_cast<long long*>(dout + 8),
+                                                     reinterpret_cast<double*>(dout + 8 + ids_b),
+                                                     reinterpret_cast<int*>(dout), reinterpret_cast<int*>(dfirst));
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
+    }
     RAG_HIP(hipStreamSynchronize(st));
     const int n = *reinterpret_cast<const int*>(hout);
     std::memcpy(out_ids, hout + 8, (size_t)n * sizeof(long long));
     std::memcpy(out_scores, hout + 8 + ids_b, (size_t)n * sizeof(double));
     *n_out = n;
+    return RAG_OK;
+}
+
+// Shared by rag_mmr (cand: C x d host rows) and rag_flat_mmr (rows of a flat index' arena).
+static int mmr_call(int C, int d, const float* cand, const long long* rows, const void* arena, int ld, int bf16,
+                    const float* q, double lambda, int top_k, const int64_t* byte_len, int64_t max_bytes,
+                    int32_t* out_order, int* out_n) {
+    hipStream_t st = lib_stream();
+    CandWs& ws = cand_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    const bool stored = rows != nullptr;
+    const size_t cand_b = stored ? al8((size_t)C * sizeof(long long)) : al8((size_t)C * d * sizeof(float));
+    const size_t q_b = al8((size_t)d * sizeof(float));
+    const size_t bytes_b = (size_t)C * sizeof(long long);
+    const size_t in_b = cand_b + q_b + bytes_b;
+    const size_t out_b = 8 + al8((size_t)C * sizeof(int));
+    const size_t nrm_b = al8((size_t)C * d * sizeof(float)), G_b = al8((size_t)C * C * sizeof(float)),
+                 simq_b = al8((size_t)C * sizeof(float));
+    int rc = ws.reserve(in_b + out_b + nrm_b + G_b + simq_b, in_b + out_b);
+    if (rc) return rc;
+    char* hin = ws.pin;
+    char* hout = ws.pin + in_b;
+    if (stored) std::memcpy(hin, rows, (size_t)C * sizeof(long long));
+    else std::memcpy(hin, cand, (size_t)C * d * sizeof(float));
+    std::memcpy(hin + cand_b, q, (size_t)d * sizeof(float));
+    std::memcpy(hin + cand_b + q_b, byte_len, bytes_b);
+    char* din = ws.dev;
+    char* dout = din + in_b;
+    char* dnrm = dout + out_b;
+    char* dG = dnrm + nrm_b;
+    char* dsimq = dG + G_b;
+    // small inputs (tens of candidates: every call the search engine makes) are read by the kernel straight
+    // from pinned memory -- each value once or twice, coalesced -- and the selection goes back the same way
+    const bool zero_copy = in_b <= ((size_t)256 << 10);
+    char* kin = zero_copy ? hin : din;
+    char* kout = zero_copy ? hout : dout;
+    if (!zero_copy) RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
+    if (stored)
+        mmr_kernel<true><<<1, CAND_THREADS, 0, st>>>(nullptr, reinterpret_cast<float*>(kin + cand_b), C, d, lambda, top_k,
+                                                    reinterpret_cast<long long*>(kin + cand_b + q_b), (long long)max_bytes,
+                                                    reinterpret_cast<float*>(dnrm), reinterpret_cast<float*>(dG),
+                                                    reinterpret_cast<float*>(dsimq), reinterpret_cast<int*>(kout + 8),
+                                                    reinterpret_cast<int*>(kout), reinterpret_cast<long long*>(kin), arena,
+                                                    ld, bf16);
+    else
+        mmr_kernel<false><<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<float*>(kin), reinterpret_cast<float*>(kin + cand_b), C,
+                                                     d, lambda, top_k, reinterpret_cast<long long*>(kin + cand_b + q_b),
+                                                     (long long)max_bytes, reinterpret_cast<float*>(dnrm),
+                                                     reinterpret_cast<float*>(dG), reinterpret_cast<float*>(dsimq),
+                                                     reinterpret_cast<int*>(kout + 8), reinterpret_cast<int*>(kout), nullptr,
+                                                     nullptr, 0, 0);
+    RAG_HIP(hipGetLastError());
+    if (!zero_copy) RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipStreamSynchronize(st));
+    const int n = *reinterpret_cast<const int*>(hout);
+    if (n > 0) std::memcpy(out_order, hout + 8, (size_t)n * sizeof(int));
+    *out_n = n;
     return RAG_OK;
 }
 
@@ -312,39 +414,28 @@ int rag_mmr(int C, int d, const float* cand, const float* q, double lambda, int 
     if (!cand || !q || !byte_len || !out_order) return fail(RAG_ERR_INVALID_ARG, "NULL buffer");
     if (C > MMR_MAX_C)
         return fail(RAG_ERR_UNSUPPORTED, "%d candidates exceed the candidate-set limit %d", C, MMR_MAX_C);
-    hipStream_t st = lib_stream();
-    CandWs& ws = cand_ws();
-    std::lock_guard<std::mutex> lk(ws.mu);
-    const size_t cand_b = (size_t)C * d * sizeof(float), q_b = al8((size_t)d * sizeof(float));
-    const size_t bytes_b = (size_t)C * sizeof(long long);
-    const size_t in_b = al8(cand_b) + q_b + bytes_b;
-    const size_t out_b = 8 + al8((size_t)C * sizeof(int));
-    const size_t nrm_b = al8(cand_b), G_b = al8((size_t)C * C * sizeof(float)), simq_b = al8((size_t)C * sizeof(float));
-    int rc = ws.reserve(in_b + out_b + nrm_b + G_b + simq_b, in_b + out_b);
+    return mmr_call(C, d, cand, nullptr, nullptr, 0, 0, q, lambda, top_k, byte_len, max_bytes, out_order, out_n);
+}
+
+int rag_flat_mmr(rag_flat_t* h, int C, const int64_t* rows, const float* q, double lambda, int top_k,
+                 const int64_t* byte_len, int64_t max_bytes, int32_t* out_order, int* out_n) {
+    RAG_REQUIRE_INIT();
+    if (!h || C < 0 || !out_n || top_k < 0) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    *out_n = 0;
+    if (C == 0 || top_k == 0) return RAG_OK;
+    if (!rows || !q || !byte_len || !out_order) return fail(RAG_ERR_INVALID_ARG, "NULL buffer");
+    if (C > MMR_MAX_C)
+        return fail(RAG_ERR_UNSUPPORTED, "%d candidates exceed the candidate-set limit %d", C, MMR_MAX_C);
+    const void* arena = nullptr;
+    int ld = 0, d = 0, bf16 = 0;
+    int64_t n = 0;
+    int rc = flat_view(h, &arena, &ld, &d, &bf16, &n);   // flushes staged rows; rows are in HBM afterwards
     if (rc) return rc;
-    char* hin = ws.pin;
-    char* hout = ws.pin + in_b;
-    std::memcpy(hin, cand, cand_b);
-    std::memcpy(hin + al8(cand_b), q, (size_t)d * sizeof(float));
-    std::memcpy(hin + al8(cand_b) + q_b, byte_len, bytes_b);
-    char* din = ws.dev;
-    char* dout = din + in_b;
-    char* dnrm = dout + out_b;
-    char* dG = dnrm + nrm_b;
-    char* dsimq = dG + G_b;
-    RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
-    mmr_kernel<<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<float*>(din), reinterpret_cast<float*>(din + al8(cand_b)), C, d,
-                                          lambda, top_k, reinterpret_cast<long long*>(din + al8(cand_b) + q_b),
-                                          (long long)max_bytes, reinterpret_cast<float*>(dnrm),
-                                          reinterpret_cast<float*>(dG), reinterpret_cast<float*>(dsimq),
-                                          reinterpret_cast<int*>(dout + 8), reinterpret_cast<int*>(dout));
-    RAG_HIP(hipGetLastError());
-    RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
-    RAG_HIP(hipStreamSynchronize(st));
-    const int n = *reinterpret_cast<const int*>(hout);
-    if (n > 0) std::memcpy(out_order, hout + 8, (size_t)n * sizeof(int));
-    *out_n = n;
-    return RAG_OK;
+    for (int i = 0; i < C; ++i)
+        if (rows[i] < 0 || rows[i] >= n)
+            return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)rows[i], (long long)n);
+    return mmr_call(C, d, nullptr, reinterpret_cast<const long long*>(rows), arena, ld, bf16, q, lambda, top_k, byte_len,
+                    max_bytes, out_order, out_n);
 }
 
 }  // extern "C"

@@ -41,6 +41,9 @@ struct Options {
     int64_t sparse_fused = 1;       // 0: BM25 / TF-IDF scoring by one launch per query term (the pre-fusion path)
 };
 Options& options();
+// flat.hip: read-only view of a flat index' arena after flushing its staged rows (rows of `ld` elements, fp32 or
+// bfloat16); valid until the next add / reset on the handle
+int flat_view(rag_flat_t* h, const void** arena, int* ld, int* d, int* bf16, int64_t* n_rows);
 int flat_init_scratch();  // flat.hip: address of the no-allocation entry point's scratch on the current device
 
 }  // namespace rag

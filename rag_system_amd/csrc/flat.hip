@@ -1357,6 +1357,18 @@ int search_device_noalloc(rag_flat* h, int64_t nq, const float* q_dev, int k, fl
 }  // namespace
 
 namespace rag {
+int flat_view(rag_flat_t* h, const void** arena, int* ld, int* d, int* bf16, int64_t* n_rows) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int rc = flush_staged(h);
+    if (rc) return rc;
+    RAG_HIP(hipStreamSynchronize(lib_stream()));
+    *arena = h->x;
+    *ld = h->ld;
+    *d = h->d;
+    *bf16 = h->dtype == RAG_DTYPE_BF16 ? 1 : 0;
+    *n_rows = h->ndev;
+    return RAG_OK;
+}
 // Called by rag_init() with the selected device current, once per process (one process per GPU).
 int flat_init_scratch() {
     int dev = -1;

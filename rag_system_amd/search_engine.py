@@ -54,7 +54,7 @@ class SearchEngine:
 
     def search_with_strategy(self, query: str, strategy="faiss", top_k=10, retrieval_mode="chunk", threshold=0.0,
                              use_knee_detection: bool = False, use_mmr: bool = False, mmr_lambda: float = 0.5,
-                             max_context_bytes: int = None) -> List[Dict[str, Any]]:
+                             max_context_bytes: int = None, mmr_reuse_index_vectors: bool = False) -> List[Dict[str, Any]]:
         strategy = strategy.lower().strip()
         retrieval_mode = retrieval_mode.lower().strip()
         self._debug("search_with_strategy strategy=%s top_k=%s mode=%s threshold=%s"
@@ -78,7 +78,7 @@ class SearchEngine:
         kept = [r for r in results if _rank_key(r) >= threshold]
         if use_mmr and kept:
             kept = self.mmr_selection(query, kept, self.embedding_manager, lambda_param=mmr_lambda, top_k=top_k,
-                                      max_context_bytes=max_context_bytes)
+                                      max_context_bytes=max_context_bytes, reuse_index_vectors=mmr_reuse_index_vectors)
         return kept
 
     # ------------------------------------------------------------------ helpers
@@ -312,15 +312,50 @@ class SearchEngine:
     # ------------------------------------------------------------------ MMR
 
     def mmr_selection(self, query: str, results: List[Dict[str, Any]], embedding_manager, lambda_param: float = 0.5,
-                      top_k: int = None, max_context_bytes: int = None) -> List[Dict[str, Any]]:
+                      top_k: int = None, max_context_bytes: int = None,
+                      reuse_index_vectors: bool = False) -> List[Dict[str, Any]]:
         """Greedy Maximal Marginal Relevance over the candidates' re-encoded texts; the cosine
-        matrix and the greedy loop run in rag_mmr (csrc/cand.hip)."""
+        matrix and the greedy loop run in rag_mmr (csrc/cand.hip).
+
+        reuse_index_vectors=True (not in the reference; default off because it can
+        change results): when every candidate is a chunk the dense index holds, its STORED row is its
+        embedding (rag_flat_mmr gathers the rows in HBM) and model.encode (search_engine.py:418) is
+        skipped.  Identical to the default whenever the stored rows equal the re-encodings up to a
+        positive factor -- MMR normalises -- which holds for rows added through embed_text / add_vector
+        and for a saved index.  Document-mode candidates (joined texts, no single row)
+        fall back to re-encoding."""
         if not results:
             return results
         top_k = top_k if top_k is not None else len(results)
         texts = [r.get("chunk", r.get("text", "")) for r in results]
-        emb = np.array(embedding_manager.model.encode(texts), dtype="float32")
         q = np.asarray(embedding_manager.embed_query(query), dtype="float32").reshape(-1)
         byte_lens = [len(t.encode("utf-8")) for t in texts]
+        if reuse_index_vectors:
+            rows = self._chunk_rows(results)
+            if rows is not None:
+                order = candidates.mmr_select_stored(self.vector_storage.index, rows, q, byte_lens, lambda_param,
+                                                     top_k, max_context_bytes)
+                return [results[i] for i in order]
+        emb = np.array(embedding_manager.model.encode(texts), dtype="float32")
         order = candidates.mmr_select(emb, q, byte_lens, lambda_param, top_k, max_context_bytes)
         return [results[i] for i in order]
+
+    def _chunk_rows(self, results):
+        """Row of the dense index for every candidate, or None if some candidate is not a stored chunk."""
+        st = self.vector_storage
+        cache = getattr(st, "_chunk_row_map", None)
+        if cache is None or cache[0] != len(st.chunks_data):
+            table = {}
+            for i, cd in enumerate(st.chunks_data):
+                table.setdefault((cd["doc_id"], cd["chunk"]), i)
+            cache = (len(st.chunks_data), table)
+            st._chunk_row_map = cache
+        if st.index.ntotal != len(st.chunks_data):
+            return None
+        rows = []
+        for r in results:
+            i = cache[1].get((r.get("doc_id"), r["chunk"])) if "chunk" in r else None
+            if i is None:
+                return None
+            rows.append(i)
+        return rows

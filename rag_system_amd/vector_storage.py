@@ -209,8 +209,19 @@ class VectorStorage:
 
     # ---- persistence (same four files, same keys) ---------------------------------------
 
-    def save(self, storage_dir, embedding_manager):
-        self.rebuild_all_indices(embedding_manager)
+    def save(self, storage_dir, embedding_manager, reencode=True):
+        """reencode=True is the reference (vector_storage.py:227 -> rebuild_faiss_index re-encodes EVERY chunk
+        with model.encode, :148-152).  reencode=False writes the vectors the index already
+        holds in HBM -- the ones add_vector received -- and only rebuilds the BM25 / TF-IDF indices; the files
+        have the same layout, the dense rows differ from a re-encoded save only where the reference's own
+        quirk makes them differ (normalised adds vs raw model outputs)."""
+        if reencode or self.index.ntotal != len(self.chunks_data):
+            self.rebuild_all_indices(embedding_manager)
+        else:
+            if "bm25" in self.indices_present:
+                self.rebuild_bm25_index()
+            if "tfidf" in self.indices_present:
+                self.rebuild_tfidf_index()
         os.makedirs(storage_dir, exist_ok=True)
         paths = {name: os.path.join(storage_dir, fn) for name, fn in _FILES.items()}
         faiss.write_index(self.index, paths["faiss"])
@@ -234,8 +245,22 @@ class VectorStorage:
         return paths["faiss"], paths["bm25"], paths["tfidf"], paths["meta"]
 
     @classmethod
-    def load(cls, storage_dir):
-        """Stores are the caller's own files (written by save() here or by the reference)."""
+    def load(cls, storage_dir, bm25_params="reference"):
+        """Stores are the caller's own files (written by save() here or by the reference).
+
+        bm25_params: the reference scores a FRESH store with Config's k1 = 1.0, b = 0.65
+        (vector_storage.py:170) but a LOADED one with rank_bm25's defaults k1 = 1.5, b = 0.75 (:305 passes
+        no parameters), so the same query ranks differently before and after a save / load cycle.
+        "reference" keeps that behaviour; "config" rebuilds with Config.BM25_PARAM_K1 / _B like a fresh
+        store; a (k1, b) tuple sets them explicitly."""
+        if bm25_params == "reference":
+            bm25_kw = {}
+        elif bm25_params == "config":
+            bm25_kw = {"k1": Config.BM25_PARAM_K1, "b": Config.BM25_PARAM_B}
+        elif isinstance(bm25_params, (tuple, list)) and len(bm25_params) == 2:
+            bm25_kw = {"k1": float(bm25_params[0]), "b": float(bm25_params[1])}
+        else:
+            raise ValueError("bm25_params must be 'reference', 'config' or a (k1, b) pair, got %r" % (bm25_params,))
         paths = {name: os.path.join(storage_dir, fn) for name, fn in _FILES.items()}
         with open(paths["meta"], "rb") as f:
             meta = pickle.load(f)
@@ -254,7 +279,7 @@ class VectorStorage:
             storage.bm25_corpus = data["bm25_corpus"]
             storage.bm25_doc_ids = data["bm25_doc_ids"]
             storage.bm25_indexed_count = data.get("bm25_indexed_count", len(storage.chunks_data))
-            storage.bm25 = BM25Okapi(storage.bm25_corpus)   # library defaults, as the reference (:305)
+            storage.bm25 = BM25Okapi(storage.bm25_corpus, **bm25_kw)   # no parameters = library defaults (:305)
         if "tfidf" in indices_present and os.path.exists(paths["tfidf"]):
             with open(paths["tfidf"], "rb") as f:
                 data = pickle.load(f)
@@ -288,15 +313,15 @@ class VectorStorageManager:
             shutil.rmtree(storage_dir)
         return True
 
-    def save_storage(self, name, base_dir, embedding_manager):
+    def save_storage(self, name, base_dir, embedding_manager, reencode=True):
         storage = self.get_storage(name)
         if not storage:
             raise ValueError("Storage '%s' non trovato." % name)
         storage.set_chunk_params(embedding_manager.chunk_size, embedding_manager.overlap)
-        storage.save(os.path.join(base_dir, name), embedding_manager)
+        storage.save(os.path.join(base_dir, name), embedding_manager, reencode=reencode)
 
-    def load_storage(self, name, base_dir):
-        storage = VectorStorage.load(os.path.join(base_dir, name))
+    def load_storage(self, name, base_dir, bm25_params="reference"):
+        storage = VectorStorage.load(os.path.join(base_dir, name), bm25_params=bm25_params)
         self.storages[name] = storage
         return storage
 

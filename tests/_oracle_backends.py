@@ -97,7 +97,8 @@ def oracle_backends():
     from rag_system_amd import bm25, candidates, faiss_compat
     faiss_compat.set_backend_factory(OracleFlatBackend)
     bm25.set_csc_factory(OracleCsc)
-    candidates.set_impl(rrf=_rrf, mmr=_mmr)
+    candidates.set_impl(rrf=_rrf, mmr=_mmr,
+                        mmr_stored=lambda b, rows, q, lam, top_k, bl, mb: _mmr(b._rows[np.asarray(rows)], q, lam, top_k, bl, mb))
     try:
         yield
     finally:

@@ -166,6 +166,69 @@ def _run_mmr_and_cross_encoder():
     assert len(tight) >= 1 and sum(len(r["chunk"].encode("utf-8")) for r in tight[1:]) <= 10
 
 
+def _run_f_rows(tmp_path):
+    """f4 MMR on the stored rows, f1 BM25 parameters of a loaded store, f3 save without re-encoding."""
+    from rag_system_amd.config import Config
+    from rag_system_amd.search_engine import SearchEngine
+    mgr, store, em = _build_store(n_docs=30, seed=17)
+    eng = SearchEngine(store, em)
+    queries = [" ".join(t) for t in zipf_queries(5, 400, seed=3)] + [store.chunks_data[2]["chunk"][:60]]
+    # f4: chunk-mode candidates are rows of the index -> same selection with and without re-encoding
+    calls = {"n": 0}
+    real_encode = em.model.encode
+
+    def counting_encode(texts, *a, **kw):
+        if not isinstance(texts, str) and len(texts) > 1:   # candidate texts (embed_query encodes one string)
+            calls["n"] += 1
+        return real_encode(texts, *a, **kw)
+    em.model.encode = counting_encode
+    try:
+        for q in queries:
+            for lam, budget in ((0.7, None), (0.3, 400), (1.0, None)):
+                base = eng.search_with_strategy(q, "faiss", 8, "chunk", use_mmr=True, mmr_lambda=lam,
+                                                max_context_bytes=budget)
+                n0 = calls["n"]
+                fast = eng.search_with_strategy(q, "faiss", 8, "chunk", use_mmr=True, mmr_lambda=lam,
+                                                max_context_bytes=budget, mmr_reuse_index_vectors=True)
+                assert calls["n"] == n0, "stored rows were available: no re-encoding expected"
+                assert fast == base
+            # document-mode candidates are joined texts: the flag falls back to re-encoding, same results
+            base = eng.search_with_strategy(q, "faiss", 5, "document", use_mmr=True)
+            n0 = calls["n"]
+            fast = eng.search_with_strategy(q, "faiss", 5, "document", use_mmr=True, mmr_reuse_index_vectors=True)
+            assert fast == base and (calls["n"] > n0 or not base)
+        # f3: save(reencode=False) writes the rows the index holds and never calls the model
+        X_mem = store.index.reconstruct_n()
+        n0 = calls["n"]
+        mgr.save_storage("s", str(tmp_path), em, reencode=False)
+        assert calls["n"] == n0
+    finally:
+        em.model.encode = real_encode
+    # f1: BM25 parameters of a loaded store
+    fresh_scores = store.bm25.get_scores(store.bm25_corpus[3][:5])
+    a = type(mgr)().load_storage("s", str(tmp_path))                               # the reference: library defaults
+    assert (a.bm25.k1, a.bm25.b) == (1.5, 0.75)
+    assert a.index.reconstruct_n().tobytes() == X_mem.tobytes()
+    b = type(mgr)().load_storage("s", str(tmp_path), bm25_params="config")         # like a fresh store
+    assert (b.bm25.k1, b.bm25.b) == (Config.BM25_PARAM_K1, Config.BM25_PARAM_B) == (1.0, 0.65)
+    assert b.bm25.get_scores(store.bm25_corpus[3][:5]).tobytes() == fresh_scores.tobytes()
+    c = type(mgr)().load_storage("s", str(tmp_path), bm25_params=(2.0, 0.5))
+    assert (c.bm25.k1, c.bm25.b) == (2.0, 0.5)
+    assert a.bm25.get_scores(store.bm25_corpus[3][:5]).tobytes() != fresh_scores.tobytes()
+    with pytest.raises(ValueError):
+        type(mgr)().load_storage("s", str(tmp_path), bm25_params="fresh")
+
+
+def test_f_rows_cpu_oracle_backend(tmp_path):
+    with oracle_backends():
+        _run_f_rows(tmp_path)
+
+
+@pytest.mark.gpu
+def test_f_rows_gpu(engine, tmp_path):
+    _run_f_rows(tmp_path)
+
+
 # ---- CPU: oracle injected, exact equality -------------------------------------------------
 
 def _run_batch_front_end():

@@ -224,6 +224,35 @@ def test_mmr_byte_budget_hand_case(engine):
     assert mmr_select(E, q, blen, 1.0, None, None) == [0, 1, 2, 3, 4, 5]
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_mmr_on_stored_rows_equals_mmr_on_uploaded_rows(engine, storage):
+    """rag_flat_mmr (candidates = rows of the index, gathered in HBM) against rag_mmr on the same values
+    handed over as host rows: the same kernel body, so the selections are identical."""
+    from oracle import dense as od
+    from rag_system_amd import faiss_compat as faiss
+    from rag_system_amd.candidates import mmr_select, mmr_select_stored
+    rng = np.random.default_rng(88)
+    n, d = 6000, 100                      # d = 100: padded rows (ld = 100 / 104)
+    X = (rng.standard_normal((n, d)) * rng.uniform(0.2, 5.0, (n, 1))).astype(np.float32)
+    X[17] = 0.0
+    idx = faiss.IndexFlat(d, 0, storage=storage)
+    idx.add(X)
+    Xs = od.bf16_round(X) if storage == "bf16" else X
+    q = rng.standard_normal(d).astype(np.float32)
+    for C, lam, top_k, budget in [(1, 0.5, None, None), (12, 0.7, 10, None), (40, 0.3, 15, 5000), (90, 1.0, 30, None),
+                                  (30, 0.0, 30, 100)]:
+        rows = rng.choice(n, C, replace=False).astype(np.int64)
+        if C > 5:
+            rows[3] = 17                  # a zero row (norm -> 1e-9 rule)
+            rows[4] = rows[2]             # the same chunk twice
+        blen = rng.integers(10, 900, C).astype(np.int64)
+        exp = mmr_select(Xs[rows], q, blen, lam, top_k, budget)
+        got = mmr_select_stored(idx, rows, q, blen, lam, top_k, budget)
+        assert got == exp, (storage, C, lam, top_k, budget)
+    with pytest.raises(ValueError):
+        mmr_select_stored(idx, [n], q, [1])
+
+
 def test_csc_large_single_term_and_many_rows(engine):
     """1M rows, a term present in every row plus rare terms: ordering among equal scores and
     the multi-block top-k / rank paths at BASELINE C5 scale."""
