@@ -17,15 +17,50 @@ import re
 
 import numpy as np
 
+import warnings
+
 _TOKEN_RE = re.compile(r"\w+|[^\w\s]", re.UNICODE)
+
+NLTK = "nltk.word_tokenize"
+FALLBACK = "regex-fallback"
+_tokenizer = None   # (name, callable), resolved once
+
+
+def _resolve():
+    """nltk.word_tokenize (punkt + treebank: what the reference uses, vector_storage.py:162,177) when nltk
+    and its punkt data are usable, else the regex fallback -- decided ONCE per process, with one warning:
+    the two differ on contractions ("don't" -> do / n't against don / ' / t), ellipses, quotes and currency,
+    so BM25 scores of a store tokenised by one and queried with the other differ from the reference's.
+    BM25 TEXT parity is therefore 'parity unpinned' without nltk; the numeric parity tests use token lists."""
+    global _tokenizer
+    if _tokenizer is None:
+        try:
+            from nltk.tokenize import word_tokenize as _nltk_tok
+            _nltk_tok("probe the punkt data, don't skip")
+            _tokenizer = (NLTK, _nltk_tok)
+        except Exception:  # nltk or its punkt data missing
+            warnings.warn("nltk (or its punkt data) is not available: BM25 text is tokenised by a regex fallback; "
+                          "scores of stores tokenised by the reference's nltk.word_tokenize are not guaranteed "
+                          "to match", RuntimeWarning, stacklevel=3)
+            _tokenizer = (FALLBACK, _TOKEN_RE.findall)
+    return _tokenizer
+
+
+def tokenizer_name():
+    return _resolve()[0]
 
 
 def word_tokenize(text):
-    try:
-        from nltk.tokenize import word_tokenize as _nltk_tok
-        return _nltk_tok(text)
-    except Exception:  # nltk or its punkt data missing
-        return _TOKEN_RE.findall(text)
+    return _resolve()[1](text)
+
+
+def check_store_tokenizer(stored_name):
+    """stored_name: metadata.pkl's "bm25_tokenizer" (None: a store the reference wrote -> nltk)."""
+    stored = stored_name or NLTK
+    if stored != tokenizer_name():
+        warnings.warn("this store's BM25 corpus was tokenised by %s but queries will be tokenised by %s: BM25 "
+                      "rankings can differ from the ones the store was built for (rebuild_bm25_index() after "
+                      "clearing bm25_corpus re-tokenises)" % (stored, tokenizer_name()), RuntimeWarning, stacklevel=3)
 
 
 class _HashingModel:

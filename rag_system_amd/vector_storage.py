@@ -26,6 +26,8 @@ import shutil
 import numpy as np
 
 from . import faiss_compat as faiss
+from . import safe_pickle
+from . import text as _text
 from .bm25 import BM25Okapi
 from .config import Config
 from .text import word_tokenize
@@ -241,7 +243,10 @@ class VectorStorage:
             pickle.dump({"embedding_dim": self.embedding_dim, "embedder": self.embedder, "doc_ids": self.doc_ids,
                          "chunks_data": self.chunks_data, "documents": self.documents,
                          "signatures": self.signatures, "indices_present": self.indices_present,
-                         "chunk_size": self.chunk_size, "overlap": self.overlap}, f)
+                         "chunk_size": self.chunk_size, "overlap": self.overlap,
+                         # not in the reference (its load() ignores unknown keys): which tokenizer split the
+                         # BM25 corpus, so that a load with another one can say so
+                         "bm25_tokenizer": _text.tokenizer_name()}, f)
         return paths["faiss"], paths["bm25"], paths["tfidf"], paths["meta"]
 
     @classmethod
@@ -263,7 +268,7 @@ class VectorStorage:
             raise ValueError("bm25_params must be 'reference', 'config' or a (k1, b) pair, got %r" % (bm25_params,))
         paths = {name: os.path.join(storage_dir, fn) for name, fn in _FILES.items()}
         with open(paths["meta"], "rb") as f:
-            meta = pickle.load(f)
+            meta = safe_pickle.load_plain(f, "metadata.pkl")     # restricted unpickling: safe_pickle.py
         indices_present = meta.get("indices_present", ["faiss"])
         storage = cls(embedding_dim=meta["embedding_dim"], embedder=meta.get("embedder", "all-MiniLM-L6-v2"),
                       indices_present=indices_present, chunk_size=meta.get("chunk_size", 100),
@@ -275,14 +280,16 @@ class VectorStorage:
         storage.index = faiss.read_index(paths["faiss"])
         if "bm25" in indices_present and os.path.exists(paths["bm25"]):
             with open(paths["bm25"], "rb") as f:
-                data = pickle.load(f)
+                data = safe_pickle.load_plain(f, "index_bm25.pkl")
+            # the corpus was tokenised when it was indexed; queries are tokenised now: same tokenizer?
+            _text.check_store_tokenizer(meta.get("bm25_tokenizer"))
             storage.bm25_corpus = data["bm25_corpus"]
             storage.bm25_doc_ids = data["bm25_doc_ids"]
             storage.bm25_indexed_count = data.get("bm25_indexed_count", len(storage.chunks_data))
             storage.bm25 = BM25Okapi(storage.bm25_corpus, **bm25_kw)   # no parameters = library defaults (:305)
         if "tfidf" in indices_present and os.path.exists(paths["tfidf"]):
             with open(paths["tfidf"], "rb") as f:
-                data = pickle.load(f)
+                data = safe_pickle.load_tfidf(f)
             storage.tfidf_index = data["tfidf_index"]
             storage.tfidf_vectorizer = data["tfidf_vectorizer"]
             storage.tfidf_doc_ids = data["tfidf_doc_ids"]
@@ -335,7 +342,7 @@ class VectorStorageManager:
                 continue
             try:
                 with open(meta_path, "rb") as f:
-                    meta = pickle.load(f)
+                    meta = safe_pickle.load_plain(f, "metadata.pkl")
                 found.append({"name": folder, "embedding_dim": meta.get("embedding_dim", 384),
                               "doc_ids": meta.get("doc_ids", []), "document_count": len(meta.get("documents", {}))})
             except Exception:

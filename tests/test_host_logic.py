@@ -337,3 +337,46 @@ def test_query_row_normalisation_is_bit_identical_to_sklearn():
         t, w = TfidfScorer._normalize_row(idx, dat)
         assert t.tolist() == qn.indices.tolist()
         assert w.tobytes() == qn.data.astype(np.float64).tobytes()
+
+
+def test_store_files_are_unpickled_restrictively(tmp_path):
+    """A store directory from elsewhere must not run code on load / on listing (safe_pickle.py)."""
+    import pickle
+    import warnings
+    from rag_system_amd import safe_pickle
+    from rag_system_amd.vector_storage import VectorStorageManager
+
+    class Boom:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    evil = pickle.dumps({"embedding_dim": 4, "documents": {"x": Boom()}})
+    with pytest.raises(pickle.UnpicklingError):
+        safe_pickle.load_plain(evil)
+    with pytest.raises(pickle.UnpicklingError):
+        safe_pickle.load_tfidf(evil)
+    (tmp_path / "bad").mkdir()
+    (tmp_path / "bad" / "metadata.pkl").write_bytes(evil)
+    assert VectorStorageManager().list_persistent_storages(str(tmp_path)) == []      # swallowed like any bad store
+    assert not (tmp_path / "pwned").exists()
+    # what a real store holds passes: plain containers, and sklearn / scipy / numpy objects for tfidf.pkl
+    from sklearn.feature_extraction.text import TfidfVectorizer
+    vec = TfidfVectorizer()
+    M = vec.fit_transform(["alpha beta", "beta gamma gamma", "delta"])
+    back = safe_pickle.load_tfidf(pickle.dumps({"tfidf_index": M, "tfidf_vectorizer": vec, "tfidf_doc_ids": ["a", "b", "c"]}))
+    assert (back["tfidf_index"] != M).nnz == 0 and back["tfidf_vectorizer"].vocabulary_ == vec.vocabulary_
+    meta = {"embedding_dim": 384, "doc_ids": ["a"], "chunks_data": [{"doc_id": "a", "chunk": "t", "source": None}],
+            "documents": {"a": {"chunks": [{"chunk": "t", "source": None}]}}, "signatures": {"s": "a"},
+            "indices_present": ["faiss", "bm25"], "chunk_size": 100, "overlap": 20}
+    assert safe_pickle.load_plain(pickle.dumps(meta)) == meta
+    with pytest.raises(pickle.UnpicklingError):
+        safe_pickle.load_plain(pickle.dumps({"m": M}))                                   # numpy is not "plain"
+    # tokenizer bookkeeping: one process-wide choice, a mismatch with the store is announced
+    from rag_system_amd import text
+    name = text.tokenizer_name()
+    assert name in (text.NLTK, text.FALLBACK) and text.tokenizer_name() == name
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        text.check_store_tokenizer(name)
+        assert not w
+        text.check_store_tokenizer(text.NLTK if name == text.FALLBACK else text.FALLBACK)
+        assert len(w) == 1 and "tokenised" in str(w[0].message)
