@@ -1063,7 +1063,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                                                        : (nq <= 128 ? 16 : 33);
         const bool filter = plan_ok && k >= filter_k && n >= opt.mfma_filter_min_rows &&
                             mfma_plan(std::max<long long>(1, n / FILTER_STEP), nq, j, bf, &ps) &&
-                            mfma_plan_filter(n, nq, bf, cap, &pf);
+                            mfma_plan_filter(n, nq, bf, cap, &pf, (int)(ld * h->esz / 4));
         // batches of up to 16 queries: the register-fed stream kernel (flat_stream.hip) takes the pass
         // over all rows, in list mode or as the filter pass; sample pass and redo stay with the tile kernel
         StreamPlan sp, sps;

@@ -22,7 +22,8 @@ struct MfmaPlan {
 // false if the MFMA path does not serve this shape (k > 128): caller falls back to the scan kernel.
 bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p);
 // Filter-mode plan (no LDS lists, any k): block shape by batch size among the filter-mode shapes.
-bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p);
+// ld_words: 4-byte words per row (block shape 10 needs a multiple of 16).
+bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p, int ld_words = 0);
 // Rows per block tile of a plan (for sizing sample passes).
 int mfma_block_rows(const MfmaPlan& p);
 // out[first + i] = ||X[first + i]||^2 for i in [0, n); ld in elements (fp32 or bfloat16 rows)

@@ -41,7 +41,7 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     const int KS = k > 64 ? 2 : 1;
     int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));  // measured per batch size (benchmarks/run_nq64_sweep.sh)
     const long long force = options().mfma_shape;
-    if (force >= 1 && force <= NSHAPES) shape = (int)force - 1;  // 9, 10: 64-query wave tiles
+    if (force >= 1 && force <= 9) shape = (int)force - 1;  // 9: 64-query wave tiles
     if (KS == 2 && SHAPES[shape].WM * SHAPES[shape].WN > 4) shape = SHAPES[shape].BK == 32 ? 6 : 2;
     int NS = 3;
     if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
@@ -80,15 +80,20 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     return true;
 }
 
-bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p) {
+bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p, int ld_words) {
     if (nq < 1 || n < 1 || cap < 1) return false;
     int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));
     const long long force = options().mfma_shape;
-    if ((force >= 1 && force <= 4) || force == 7 || force == 8 || force == 9) shape = (int)force - 1;
+    if ((force >= 1 && force <= 4) || (force >= 7 && force <= 10)) shape = (int)force - 1;
     int NS = 3;
     if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
+    if (shape == 9) {  // pipelined kernel: fixed rings (3 row stages, 2 query stages), whole 128-byte lines
+        if (ld_words % 32 != 0) shape = 3;
+        else NS = 3;
+    }
     const Shape& sh = SHAPES[shape];
     int bpc = sh.bpc;
+    if (shape != 9)
     while (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.NT, sh.BK, NS, 0) * bpc > 160 * 1024) {
         if (NS > 2) --NS;
         else if (bpc > 1) --bpc;

@@ -513,6 +513,8 @@ constexpr Shape SHAPES[] = {
     {1, 8, 8, 1, 32, 1},  // 8: 256 queries
     {2, 4, 4, 2, 16, 1},  // 9: 256 queries x 256 rows, wave tile 128 rows x 64 queries (6 fragment reads per
                           //    8 MFMAs instead of 9); measured equal to shape 4, kept as an option
+    {2, 4, 4, 2, 32, 1},  // 10: the same tile with the software-pipelined K loop of flat_mfma_pipe.h
+                          //    (filter mode only, rows of whole 128-byte lines)
 };
 constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
@@ -520,6 +522,24 @@ constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 // (flat_mfma_f32.hip / flat_mfma_bf16.hip).  List mode: KS = 2 (64 < k <= 128) exists for the
 // 4-wave shapes only (eight waves' lists of that length do not fit the LDS).  Filter mode holds
 // no lists and is built for the 64-byte-row shapes (1-4, 9) and the 128-byte-row shapes 7, 8.
+}  // namespace mfma
+}  // namespace rag
+#include "flat_mfma_pipe.h"
+namespace rag {
+namespace mfma {
+
+template <bool BF>
+int launch_pipe(const MfmaPlan& p, const Args& a) {
+    const size_t smem = pipe_smem_need();
+    auto fn = a.metric == RAG_METRIC_IP ? flat_pipe_kernel<RAG_METRIC_IP, BF> : flat_pipe_kernel<RAG_METRIC_L2, BF>;
+    RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    fn<<<(unsigned)(p.S * p.col_tiles), 512, smem, a.st>>>(a.X, a.n, a.ld, a.Qp, a.nq, p.S, p.col_tiles, a.cand_key,
+                                                          a.cand_id, a.xnorm, a.qnorm, a.zero16, (long long)p.tile_step,
+                                                          a.run_flag, a.thr_q, a.counts, p.cap);
+    RAG_HIP(hipGetLastError());
+    return RAG_OK;
+}
+
 template <bool BF>
 int dispatch(const MfmaPlan& p, const Args& a) {
 #define RAG_MFMA_NS(WM, WN, MT, NT, BK, KS, FILT)                               \
@@ -535,6 +555,9 @@ int dispatch(const MfmaPlan& p, const Args& a) {
             case 6: return RAG_MFMA_NS(1, 4, 8, 1, 32, 1, true);
             case 7: return RAG_MFMA_NS(1, 8, 8, 1, 32, 1, true);
             case 8: return RAG_MFMA_NS(2, 4, 4, 2, 16, 1, true);
+            case 9:
+                if (a.ld % 32 != 0) return fail(RAG_ERR_INVALID_ARG, "block shape 10 needs rows of whole 128-byte stages");
+                return launch_pipe<BF>(p, a);
             default: return fail(RAG_ERR_INVALID_ARG, "no filter-mode kernel for block shape %d", p.shape + 1);
         }
     }
@@ -547,6 +570,7 @@ int dispatch(const MfmaPlan& p, const Args& a) {
         case 5: return RAG_MFMA_4W(2, 2, 4, 32);
         case 6: return RAG_MFMA_4W(1, 4, 8, 32);
         case 7: return RAG_MFMA_NS(1, 8, 8, 1, 32, 1, false);
+        case 9: return fail(RAG_ERR_INVALID_ARG, "block shape 10 is a filter-mode shape");
         default: return RAG_MFMA_NS(2, 4, 4, 2, 16, 1, false);
     }
 #undef RAG_MFMA_4W

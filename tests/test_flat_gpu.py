@@ -470,6 +470,43 @@ def test_mfma_filter_mode_matches_oracle(engine, storage):
         _with_options(lib, {"mfma_filter_k": 0, "mfma_filter_min_rows": 1 << 19})
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_pipelined_filter_kernel_equals_tile_kernel(engine, storage):
+    """Block shape 10 (flat_mfma_pipe.h: software-pipelined K loop, 3- and 4-stage ring) against
+    the oracle and bit-for-bit against shape 4 (same K order per accumulator), both metrics, with
+    partial last row tiles, fewer queries than a block's 256 columns, and several query tiles."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(777)
+    rnd = od.bf16_round if storage == "bf16" else (lambda a: a)
+    try:
+        _with_options(lib, {"mfma_filter_k": 1, "mfma_filter_min_rows": 1, "wide_max_nq": -1})
+        for metric in (0, 1):
+            for n, d in [(70_001, 64), (33_000, 384)]:   # rows of 2 / 12 (bf16) or 4 / 24 (fp32) K stages
+                X = _rand_unit(rng, n, d)
+                X[n // 2] = X[3]
+                X[n - 1] = X[3]
+                idx = faiss.IndexFlat(d, metric, storage=storage)
+                idx.add(X)
+                Xr = rnd(X)
+                for nq, k in [(130, 50), (300, 100), (600, 10)]:
+                    Q = _rand_unit(rng, nq, d)
+                    Q[0] = X[3]
+                    Qr = rnd(Q)
+                    _with_options(lib, {"mfma_shape": 4, "mfma_stages": 0})
+                    D0, I0 = idx.search(Q, k)
+                    assert "tile filter" in idx._b.last_kernel(), idx._b.last_kernel()
+                    _, Ir, D64 = od.flat_search(Xr, Qr, k, metric)
+                    for stages in (0, 3):
+                        _with_options(lib, {"mfma_shape": 10, "mfma_stages": stages})
+                        D, I = idx.search(Q, k)
+                        od.check_topk(D, I, D64, Ir, RTOL, ATOL if metric == 0 else 4e-6, _scorer(Xr, Qr, metric))
+                        assert np.array_equal(I, I0) and np.array_equal(D, D0), (metric, n, d, nq, k, stages)
+    finally:
+        _with_options(lib, {"mfma_filter_k": 0, "mfma_filter_min_rows": 1 << 19, "wide_max_nq": 0, "mfma_shape": 0,
+                            "mfma_stages": 0})
+
+
 def test_mfma_filter_mode_default_thresholds(engine):
     """600k x 64 rows, k = 50: filter mode by default; identical ids to list mode."""
     from rag_system_amd import _lib
