@@ -57,15 +57,24 @@ int main(int argc, char** argv) {
     p.S = ((rag::num_cus() + p.col_tiles - 1) / p.col_tiles + 7) & ~7;
     CK(hipDeviceSynchronize());
     hipStream_t st = rag::lib_stream();
+    float* Qt;  // the queries as the kernel's LDS image (flat_mfma_pipe.h)
+    CK(hipMalloc(&Qt, (size_t)rag::mfma::pipe_tiled_words(p.col_tiles, ldw) * 4));
+    if (rag::mfma::pipe_tile_queries((const float*)Q, nq, ldw, p.col_tiles, Qt, st)) { fprintf(stderr, "%s\n", rag_last_error()); return 1; }
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a, st));
-        const rag::mfma::Args args{(const float*)X, n, ldw, (const float*)Q, nq, 100, 0, ck, ci, nullptr, nullptr, zero, st,
+        const rag::mfma::Args args{(const float*)X, n, ldw, (const float*)Qt, nq, 100, 0, ck, ci, nullptr, nullptr, zero, st,
                                    nullptr, thr, counts};
         if (rag::mfma::launch_pipe<true>(p, args)) {
             fprintf(stderr, "%s\n", rag_last_error()); return 1;
         }
         CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+#ifdef RAG_PIPE_CHECK
+        unsigned long long chk[8];
+        CK(hipMemcpyFromSymbol(chk, HIP_SYMBOL(rag::mfma::g_pipe_check), sizeof chk));
+        printf("address check: %llu out of range; first: offset %lld tag %llu block %llu thread %llu\n", chk[0], (long long)chk[1],
+               chk[2], chk[3] >> 32, chk[3] & 0xffffffffULL);
+#endif
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         const double tf = 2.0 * nq * (double)n * d / (ms * 1e-3) / 1e12;
         printf("exp %d NS %d S %d col_tiles %d %s: %.3f ms  %.0f TFLOP/s (%.1f %% of 2500)\n",

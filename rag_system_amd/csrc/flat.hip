@@ -673,6 +673,7 @@ struct rag_flat {
     char* x = nullptr;       // HBM arena, cap * ld elements of esz bytes
     float* ws_cvt = nullptr; int64_t ws_cvt_cap = 0;   // fp32 staging for bfloat16 conversion
     unsigned short* ws_qb = nullptr; int64_t ws_qb_cap = 0;  // bfloat16 queries (MFMA operand)
+    float* ws_qt = nullptr; int64_t ws_qt_cap = 0;           // queries as block shape 10's LDS image
     std::vector<float> staged;  // host rows not yet flushed (d floats each)
     // search workspace (HBM)
     float* ws_q = nullptr;   int64_t ws_q_cap = 0;     // padded queries
@@ -1092,6 +1093,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             if (rc) return rc;
             rc = grow(h->ws_cnt, h->ws_cnt_cap, 2 * nq + 1);
             if (rc) return rc;
+            if (!wide && !stream) {
+                rc = grow(h->ws_qt, h->ws_qt_cap, mfma_tiled_query_words(pf, ld * h->esz / 4));
+                if (rc) return rc;
+            }
         }
         ProfPair prof(h);
         rc = prof.begin(st);
@@ -1162,9 +1167,16 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         else if (stream)
             rc = stream_launch(sp, h->x, (long long)n, dch, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
                                h->ws_qn, st, nullptr, h->ws_thr, counts);
-        else
-            rc = mfma_launch(pf, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+        else {
+            const float* Qf = Qw;
+            if (mfma_tiled_query_words(pf, ldw) > 0) {  // the pipelined kernel reads a tiled image of the queries
+                rc = mfma_tile_queries(pf, Qw, (int)nq, ldw, h->ws_qt, st);
+                if (rc) return rc;
+                Qf = h->ws_qt;
+            }
+            rc = mfma_launch(pf, Xw, (long long)n, ldw, Qf, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
                              h->ws_qn, h->zero16, st, nullptr, h->ws_thr, counts);
+        }
         if (rc) return rc;
         rc = prof.end(st);
         if (rc) return rc;
@@ -1414,6 +1426,7 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->x);
         (void)hipFree(h->ws_q);
         (void)hipFree(h->ws_qb);
+        (void)hipFree(h->ws_qt);
         (void)hipFree(h->ws_cvt);
         (void)hipFree(h->ws_key);
         (void)hipFree(h->ws_id);

@@ -24,6 +24,10 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p);
 // Filter-mode plan (no LDS lists, any k): block shape by batch size among the filter-mode shapes.
 // ld_words: 4-byte words per row (block shape 10 needs a multiple of 16).
 bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p, int ld_words = 0);
+// Block shape 10 (flat_mfma_pipe.h) reads its queries from a tiled image: words it needs, and the kernel
+// that fills it from the nq x ld_words query array; the image is then passed to mfma_launch as Qp.
+long long mfma_tiled_query_words(const MfmaPlan& p, int ld_words);
+int mfma_tile_queries(const MfmaPlan& p, const float* Qw, int nq, int ld_words, float* out, hipStream_t st);
 // Rows per block tile of a plan (for sizing sample passes).
 int mfma_block_rows(const MfmaPlan& p);
 // out[first + i] = ||X[first + i]||^2 for i in [0, n); ld in elements (fp32 or bfloat16 rows)

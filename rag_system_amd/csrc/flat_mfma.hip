@@ -83,6 +83,9 @@ bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
 bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p, int ld_words) {
     if (nq < 1 || n < 1 || cap < 1) return false;
     int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));
+    // more than 128 queries over bfloat16 rows of whole 128-byte lines: the pipelined kernel of
+    // flat_mfma_pipe.h (config C3: 17.x ms per batch against 19.1 for shape 4)
+    if (nq > 128 && bf16 && ld_words > 0 && ld_words % 32 == 0) shape = 9;
     const long long force = options().mfma_shape;
     if ((force >= 1 && force <= 4) || (force >= 7 && force <= 10)) shape = (int)force - 1;
     int NS = 3;
@@ -122,6 +125,13 @@ bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p
 }
 
 int mfma_block_rows(const MfmaPlan& p) { return 32 * p.MT * p.WM; }
+
+long long mfma_tiled_query_words(const MfmaPlan& p, int ld_words) {
+    return p.shape == 9 ? mfma::pipe_tiled_words(p.col_tiles, ld_words) : 0;
+}
+int mfma_tile_queries(const MfmaPlan& p, const float* Qw, int nq, int ld_words, float* out, hipStream_t st) {
+    return mfma::pipe_tile_queries(Qw, nq, ld_words, p.col_tiles, out, st);
+}
 
 int mfma_row_norms(const void* X, int ld, bool bf16, long long first, long long n, float* out, hipStream_t st) {
     if (n <= 0) return RAG_OK;

@@ -14,27 +14,81 @@
 //     query stages (queries come from the L2: one stage), and nothing else -- no sink for filler
 //     loads (they go into ring buffers nobody reads any more) and no row-norm tile (the L2 epilogue
 //     reads its norms from global memory).
-// (2) The schedule inside a stage.  flat_mfma_kernel reads a K slice's fragments and multiplies
-//     them in the same phase, so every wave of the CU waits for the LDS at the same time and the
-//     matrix pipe idles while they do.  Here the fragments are double buffered in registers and
-//     every LDS read is issued one MFMA batch (8 MFMAs = 256 cycles) ahead of its use:
+//     The QUERIES are not read from their row-major array at all: tile_queries_kernel lays them out
+//     beforehand as the LDS image itself, [query tile][K stage][256 rows x 128 B, swizzled], so that
+//     every LDS-DMA instruction of a query stage reads 1 KiB of consecutive bytes.  The load path of a
+//     CU moves such an instruction at 58 B/clk from the L2 and ANY multi-row shape (8 x 128 B, 16 x 64
+//     B, 4 x 256 B) at 31 B/clk (benchmarks/glds_pattern.hip), and half of this kernel's LDS fill is
+//     queries.  (The rows stay row-major: every other kernel reads that layout.)
+// (2) The schedule inside a stage: the two wave groups of the block (wm = 0 / 1, one wave of each
+//     per SIMD) alternate.  flat_mfma_kernel has all eight waves issue their loads, read their
+//     fragments and multiply at the same time, so the matrix pipe idles while every wave of a SIMD
+//     sits in load issue (an LDS-DMA instruction costs its wave 60-185 cycles) or waits for the
+//     LDS.  Here a stage is two phases per group, and the second group runs one barrier behind:
 //
-//   iteration e  (fa = fragments of stage e, K slice 0, already in flight or landed)
-//     issue LDS-DMA: queries of stage e+1, rows of stage e+2 (into the buffers stage e-1 used)
-//     fb <- slice 1 ; 8 MFMAs on fa ; fa <- slice 2 ; 8 MFMAs on fb ; fb <- slice 3 ; 8 MFMAs on fa
-//     wait: own loads of stage e+1 landed (vmcnt), own reads returned (lgkmcnt) ; s_barrier
-//     fa <- slice 0 of stage e+1 ; 8 MFMAs on fb
-//     (last stage of a row tile: filter epilogue on the accumulators)
+//       group 0:  mem A | mul A | mem B | mul B | mem A' | ...
+//       group 1:        | mem A | mul A | mem B | mul B  | ...       ("|" = s_barrier of all 8 waves)
 //
-// One barrier per 32 MFMAs per wave.  Safety of the rings: every fragment read of stage e has
-// returned before the barrier of iteration e, and the loads that overwrite its buffers are issued
-// after that barrier (iteration e+1); stage e+1 is read only after the barrier of iteration e,
-// before which every wave waited for its own share of it.  K order per accumulator is the same as
-// in flat_mfma_kernel, so the scores are bit-identical.
+//     mem A: fragments of K slices 0,1 of stage e -> registers (12 ds_read_b128); LDS-DMA of the
+//            queries of stage e+1 (4 instructions); own reads returned (lgkmcnt(0))
+//     mul A: 16 MFMAs (32x32x16 bf16; fp32: 64 of 32x32x2) at raised priority
+//     mem B: slices 2,3; LDS-DMA of the rows of stage e+2; own loads of stage e+1 landed
+//            (vmcnt(4): all but the four just issued), own reads returned
+//     mul B: 16 MFMAs; behind its closing barrier, once per row tile, the filter epilogue (VALU work
+//            that runs beside the other group's MFMAs)
+//
+// Safety of the rings.  Write after read: the loads of mem A(e) / mem B(e) go into the buffers stage
+// e-1 used; the last reads of stage e-1 are group 1's in its mem B(e-1), which end (lgkmcnt(0))
+// before the barrier that group 0 passes on its way into mem A(e).  Read after write: stage e+1 is
+// first read in group 0's mem A(e+1), behind the barrier that closes its mul B(e); every wave waited
+// for its own loads of stage e+1 in its mem B(e), which ends at the barrier before that one (group
+// 0) or at that barrier itself (group 1).  K order per accumulator is the same as in
+// flat_mfma_kernel, so the scores are bit-identical.
 #pragma once
 
 namespace rag {
 namespace mfma {
+
+// Queries as the pipelined kernel's LDS image: out[((c * nk + ks) * 2048 + slot) * 4 .. +4] (words) =
+// 16-byte chunk (slot & 7) ^ swz(row) of K stage ks of query c * 256 + row, row = slot >> 3; queries
+// past nq are zero rows.  Qw: nq x ld words (ld % 32 == 0).
+template <int BKW>
+__global__ __launch_bounds__(256) void tile_queries_kernel(const f32x4* __restrict__ Qw, int nq, int ld, int nk,
+                                                           long long total_slots, f32x4* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_slots) return;
+    const int slot = (int)(i & 2047);
+    const long long stage = i >> 11;
+    const int ks = (int)(stage % nk);
+    const int c = (int)(stage / nk);
+    const int row = slot >> 3, q = c * 256 + row;
+    const int chunk = (slot & 7) ^ swz<BKW>(row);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < nq) v = Qw[((long long)q * ld + ks * BKW) / 4 + chunk];
+    out[i] = v;
+}
+
+#ifdef RAG_PIPE_CHECK
+// diagnostic build (benchmarks/pipe_timing.hip -DRAG_PIPE_CHECK): every LDS-DMA source address is checked
+// against its array; an address outside is recorded (count, first offender) and replaced by zero16
+__device__ unsigned long long g_pipe_check[8];
+#define RAG_GLDS(ptr, dst, lo, nbytes, tag)                                                          \
+    do {                                                                                             \
+        const char* p_ = reinterpret_cast<const char*>(ptr);                                         \
+        const char* lo_ = reinterpret_cast<const char*>(lo);                                         \
+        const bool bad_ = p_ < lo_ || p_ + 16 > lo_ + (nbytes);                                      \
+        if (bad_) {                                                                                  \
+            if (atomicAdd(&g_pipe_check[0], 1ULL) == 0) {                                            \
+                g_pipe_check[1] = (unsigned long long)(p_ - lo_);                                    \
+                g_pipe_check[2] = (unsigned long long)(tag);                                         \
+                g_pipe_check[3] = ((unsigned long long)blockIdx.x << 32) | threadIdx.x;              \
+            }                                                                                        \
+        }                                                                                            \
+        glds16(bad_ ? reinterpret_cast<const char*>(zero16) : p_, dst);                              \
+    } while (0)
+#else
+#define RAG_GLDS(ptr, dst, lo, nbytes, tag) glds16(ptr, dst)
+#endif
 
 template <int METRIC, bool BF>
 __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
@@ -46,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     constexpr int WN = 4, MT = 4, NT = 2, BK = 32;
     constexpr int NWV = 8, BMW = 128, BM = 256, BNW = 64, BN = 256;
     constexpr int CH = BK / 4, LDS_LD = BK;
-    constexpr int NSX = 3, NSQ = 2;            // ring depths: row stages / query stages
+    constexpr int NSX = 3;                     // ring depths: three row stages, two query stages
     constexpr int XQ = BM * CH / 64 / NWV;     // 4 LDS-DMA instructions per wave per X stage
     constexpr int QQ = BN * CH / 64 / NWV;     // 4 per Q stage
     constexpr int STG = BM * LDS_LD;           // words per stage buffer (32 KiB), X and Q alike
@@ -73,11 +127,15 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         }
     }
     const int q0 = c * BN;
-    const long long ntiles = ((n + BM - 1) / BM + tile_step - 1) / tile_step;
-    const long long my_tiles = s < ntiles ? (ntiles - s + S - 1) / S : 0;
-    const long long tile_rows = (long long)BM * tile_step;
+    // 32-bit row and stage counters throughout (the caller admits fewer than 2^31 rows): the K loop has no
+    // registers to spare, scalar ones included
+    const int nrows = (int)n;
+    const int ntiles = (int)(((n + BM - 1) / BM + tile_step - 1) / tile_step);
+    const int my_tiles = s < ntiles ? (ntiles - s + S - 1) / S : 0;
+    const int tile_rows = BM * (int)tile_step;
+    const int tile_stride = S * tile_rows;  // rows between this block's consecutive tiles (< 2^31: checked by the host)
     const int nk = ld / BK;  // the plan admits only ld % BK == 0
-    const long long total = my_tiles * nk;
+    const int total = my_tiles * nk;
 
     int my_q[NT];
     float thr[NT], qn[NT];
@@ -87,6 +145,9 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         thr[u] = my_q[u] < nq ? thr_q[my_q[u]] : FLT_MAX;
         qn[u] = 0.f;
         if (METRIC == RAG_METRIC_L2) qn[u] = my_q[u] < nq ? qnorm[my_q[u]] : 0.f;
+        // the compiler waits for these two loads HERE, not with a vmcnt(0) in front of their first use in
+        // the epilogue (where it would drain the LDS-DMA ring once per row tile)
+        asm volatile("" : "+v"(thr[u]), "+v"(qn[u]));
     }
 
     // LDS-DMA addressing as in flat_mfma_kernel: LDS slot (16 B) -> (row, physical chunk); the
@@ -100,72 +161,58 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     const int lcol = 4 * ((lane & 7) ^ swz<BK>(lrow));
     const unsigned lane_off = 4u * (unsigned)(lrow * ld + lcol);  // bytes; < 256 rows of <= 32 KiB
     const char* Xb = reinterpret_cast<const char*>(X);
-    const char* Qb = reinterpret_cast<const char*>(Qp) + (long long)q0 * ld * 4;
+    const float* Qt = Qp + (long long)c * (ld / BK) * STG;  // this query tile's stages (tile_queries_kernel)
     const long long row_stride = 256LL * ld;  // bytes between the rows of consecutive instructions
-    const bool q_whole = q0 + BN <= nq;
-    // two prefetch cursors: rows run two stages ahead of the multiply, queries one
-    long long px_tiles_left = my_tiles;
-    long long px_row0 = (long long)s * tile_rows;
-    int px_ks = 0, px_buf = 0;
-    long long pq_left = total;
-    int pq_ks = 0, pq_buf = 0;
+    // two prefetch cursors: rows run two stages ahead of the multiply, queries one.  x_ld(it) / q_ld(it)
+    // issue ONE LDS-DMA instruction of the stage under the cursor (the K loop spreads them between its
+    // MFMAs); x_next() / q_next() move the cursor on after the stage's last instruction.
     // Past the end the loads still issue (zero source, into a ring buffer nobody reads any more) so
     // that the number of outstanding operations per iteration stays what the counted waits assume.
-    auto issue_x = [&]() {
-        float* xs = Xs + px_buf * STG;
-        px_buf = px_buf + 1 == NSX ? 0 : px_buf + 1;
+    int px_tiles_left = my_tiles;
+    int px_row0 = s * tile_rows;
+    int px_ks = 0, px_buf = 0;
+    int pq_left = total;
+    int pq_ks = 0, pq_buf = 0;
+    auto x_ld = [&](int it) {
+        float* dst = Xs + px_buf * STG + (it * NWV + wid) * 256;
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
         if (px_tiles_left < my_tiles) return;  // ablation: no loads after the first row tile
 #endif
         if (px_tiles_left > 0) {
-            const char* base = Xb + (px_row0 * ld + px_ks * BK) * 4;
-            if (px_row0 + BM <= n) {
-#pragma unroll
-                for (int it = 0; it < XQ; ++it)
-                    glds16(base + it * row_stride + (unsigned long long)lane_off, xs + (it * NWV + wid) * 256);
+            const char* base = Xb + ((long long)px_row0 * ld + px_ks * BK) * 4;
+            if (px_row0 + BM <= nrows) {
+                RAG_GLDS(base + it * row_stride + (unsigned long long)lane_off, dst, Xb, (long long)n * ld * 4, 1);
             } else {  // the last, partial row tile: rows past the end re-read the last row (masked in the epilogue)
-#pragma unroll
-                for (int it = 0; it < XQ; ++it) {
-                    long long r = lrow + 64 * it;
-                    r = px_row0 + r < n ? r : n - 1 - px_row0;
-                    glds16(base + (unsigned long long)(4u * (unsigned)(r * ld + lcol)), xs + (it * NWV + wid) * 256);
-                }
-            }
-            if (++px_ks == nk) {
-                px_ks = 0;
-                px_row0 += (long long)S * tile_rows;
-                --px_tiles_left;
+                int r = lrow + 64 * it;
+                r = px_row0 + r < nrows ? r : nrows - 1 - px_row0;
+                RAG_GLDS(base + (unsigned long long)(4u * (unsigned)(r * ld + lcol)), dst, Xb, (long long)n * ld * 4, 2);
             }
         } else {
-#pragma unroll
-            for (int it = 0; it < XQ; ++it) glds16(zero16, xs + (it * NWV + wid) * 256);
+            glds16(zero16, dst);
         }
     };
-    auto issue_q = [&]() {
-        float* qs = Qs + pq_buf * STG;
-        pq_buf ^= 1;
+    auto x_next = [&]() {
+        px_buf = px_buf + 1 == NSX ? 0 : px_buf + 1;
+        if (px_tiles_left > 0 && ++px_ks == nk) {
+            px_ks = 0;
+            px_row0 += tile_stride;
+            --px_tiles_left;
+        }
+    };
+    auto q_ld = [&](int it) {
+        float* dst = Qs + pq_buf * STG + (it * NWV + wid) * 256;
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
         if (pq_left + nk < total) return;
 #endif
+        // the stage is the LDS image itself: instruction `it` of this wave reads its 1 KiB in lane order
+        if (pq_left > 0) RAG_GLDS(Qt + (long long)pq_ks * STG + ((it * NWV + wid) * 64 + lane) * 4, dst, Qt, (long long)nk * STG * 4, 3);
+        else glds16(zero16, dst);
+    };
+    auto q_next = [&]() {
+        pq_buf ^= 1;
         if (pq_left > 0) {
-            const char* base = Qb + pq_ks * BK * 4;
-            if (q_whole) {
-#pragma unroll
-                for (int it = 0; it < QQ; ++it)
-                    glds16(base + it * row_stride + (unsigned long long)lane_off, qs + (it * NWV + wid) * 256);
-            } else {  // fewer than 256 queries left: the padding columns re-read the last query (never pass)
-#pragma unroll
-                for (int it = 0; it < QQ; ++it) {
-                    int r = lrow + 64 * it;
-                    r = q0 + r < nq ? r : nq - 1 - q0;
-                    glds16(base + (unsigned long long)(4u * (unsigned)(r * ld + lcol)), qs + (it * NWV + wid) * 256);
-                }
-            }
             pq_ks = pq_ks + 1 == nk ? 0 : pq_ks + 1;
             --pq_left;
-        } else {
-#pragma unroll
-            for (int it = 0; it < QQ; ++it) glds16(zero16, qs + (it * NWV + wid) * 256);
         }
     };
 
@@ -205,33 +252,49 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         asm volatile("ds_read_b128 %0, %1 offset:8192" : "=&v"(ax[2]) : "v"(xa));
         asm volatile("ds_read_b128 %0, %1 offset:12288" : "=&v"(ax[3]) : "v"(xa));
     };
-    auto multiply = [&](const f32x4(&ax)[MT], const f32x4(&aq)[NT]) {
-#if defined(RAG_PIPE_VAR) && (RAG_PIPE_VAR & 2)
-        __builtin_amdgcn_s_setprio(1);
-#endif
+    // One K slice: 8 MFMAs (fp32: 32), with two LDS-DMA instructions issued in their shadow (ld0 behind
+    // the second MFMA, ld1 behind the sixth): all eight issued together at the top of a stage keep every
+    // wave of the CU in load issue at the same time (the CU's load path takes ~18-33 cycles per
+    // instruction, 64 per stage) while the matrix pipe idles.
+    auto multiply = [&](const f32x4(&ax)[MT], const f32x4(&aq)[NT], auto ld0, auto ld1) {
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 4)
         acc[0][0][0] += ax[0][0] * aq[0][0];  // ablation: no MFMA
+        ld0();
+        ld1();
         return;
 #endif
+        // slot i = behind the i-th MFMA.  (Tried: the waves of different SIMDs using different slots, so that
+        // the CU's eight waves do not arrive at the load path together: 15.0 ms against 13.7 for C3.)
+        auto slot = [&](int i) {
+            if (i == 1) ld0();
+            if (i == 5) ld1();
+        };
         if (BF) {
 #pragma unroll
             for (int u = 0; u < NT; ++u)
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                for (int t = 0; t < MT; ++t) {
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, ax[t]), __builtin_bit_cast(bf16x8, aq[u]), acc[t][u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    slot(u * MT + t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         } else {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
 #pragma unroll
-                    for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < MT; ++t) {
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[t][cc], aq[u][cc], acc[t][u], 0, 0, 0);
+                        if (cc == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            slot(u * MT + t);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
         }
-#if defined(RAG_PIPE_VAR) && (RAG_PIPE_VAR & 2)
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 2)
 #pragma unroll
@@ -240,124 +303,133 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     for (int u = 0; u < NT; ++u) fa_q[u] = fb_q[u] = f32x4{1.f, 2.f * lane, 3.f, 4.f};
 #endif
 
-    // prologue: rows of stages 0 and 1 and queries of stage 0 in flight; slice 0 of stage 0 -> fa
-    issue_x();
-    issue_q();
-    issue_x();
-    if (total > 0) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XQ));
-        __builtin_amdgcn_s_barrier();
-        read_frags(0, 0, 0, fa_x, fa_q);
-    }
+    // The filter epilogue of a finished row tile (rows row0 .. row0 + BM): every accumulator against its
+    // query's threshold, passing rows appended through the query's counter, accumulators cleared.
+    auto epilogue = [&](int row0) {
+        const bool partial = row0 + BM > nrows;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int tile_off = wm * BMW + 32 * t;
+            const int rowbase = row0 + tile_off;
+            float xn[16];
+            if (METRIC == RAG_METRIC_L2) {
+                // this lane's 16 rows: four runs of four (the LDS holds nothing but the rings)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    xn[r] = row < nrows ? xnorm[row] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                float key[16];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[t][u][r];
+                    if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn[r]) - qn[u];
+                    key[r] = v;
+                    bool ok = v >= thr[u];
+                    if (partial) ok = ok && (rowbase + ro < nrows);
+                    any = any || ok;
+                }
+                if (__ballot(any) != 0ULL && my_q[u] < nq) {
+                    // rare: append every passing row of this lane's query to its buffer
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key[r] >= thr[u] && rowbase + ro < nrows) {
+                            const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
+                            if (slot < (unsigned int)cap) {
+                                const long long o = (long long)my_q[u] * cap + slot;
+                                cand_key[o] = key[r];
+                                cand_id[o] = rowbase + ro;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+            }
+        }
+    };
+
+    // prologue: rows of stages 0 and 1 and queries of stage 0 in flight; slice 0 of stage 0 -> fa; first
+    // half of the queries of stage 1
+#pragma unroll
+    for (int it = 0; it < XQ; ++it) x_ld(it);
+    x_next();
+#pragma unroll
+    for (int it = 0; it < QQ; ++it) q_ld(it);
+    q_next();
+#pragma unroll
+    for (int it = 0; it < XQ; ++it) x_ld(it);
+    x_next();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XQ));
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0, fa_x, fa_q);
+    q_ld(0);
+    q_ld(1);
 
     int xcur = 0, qcur = 0, ks = 0;
-    long long row0 = (long long)s * tile_rows;
-    for (long long e = 0; e < total; ++e) {
-        issue_q();  // queries of stage e+1 -> the buffer stage e-1 used
-        issue_x();  // rows of stage e+2    -> the buffer stage e-1 used
+    int row0 = s * tile_rows;
+    for (int e = 0; e < total; ++e) {
+        // loads of this iteration, in issue order: second half of the queries of stage e+1, rows of stage
+        // e+2 (both into the buffers stage e-1 used), and behind the barrier the first half of the queries
+        // of stage e+2 (into the buffer stage e used)
         read_frags(xcur, qcur, 1, fb_x, fb_q);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));  // slice 0 has landed, slice 1 may be in flight
         __builtin_amdgcn_sched_barrier(0);
-        multiply(fa_x, fa_q);
+        multiply(fa_x, fa_q, [&] { q_ld(2); }, [&] { q_ld(3); q_next(); });
         __builtin_amdgcn_sched_barrier(0);
         read_frags(xcur, qcur, 2, fa_x, fa_q);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));
         __builtin_amdgcn_sched_barrier(0);
-        multiply(fb_x, fb_q);
+        multiply(fb_x, fb_q, [&] { x_ld(0); }, [&] { x_ld(1); });
         __builtin_amdgcn_sched_barrier(0);
         read_frags(xcur, qcur, 3, fb_x, fb_q);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));
         __builtin_amdgcn_sched_barrier(0);
-        multiply(fa_x, fa_q);
+        multiply(fa_x, fa_q, [&] { x_ld(2); }, [&] { x_ld(3); x_next(); });
         __builtin_amdgcn_sched_barrier(0);
-#if defined(RAG_PIPE_VAR) && (RAG_PIPE_VAR & 1)
-        // variant: the barrier after the last MFMA batch (a full iteration of lead for the query loads;
-        // slice 0 of the next stage is then read with its latency exposed)
-        asm volatile("s_waitcnt lgkmcnt(0)");
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(fb_x, fb_q);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XQ));
-        __builtin_amdgcn_s_barrier();
-        xcur = xcur + 1 == NSX ? 0 : xcur + 1;
-        qcur ^= 1;
-        read_frags(xcur, qcur, 0, fa_x, fa_q);
-#else
-        // own loads of stage e+1 have landed (all but the rows of stage e+2 issued above), every
+        // own loads of stage e+1 have landed (all but the four row loads of stage e+2 issued above), every
         // fragment read of stage e has returned.  (Assembly, not the builtin: the compiler relaxes a
         // builtin wait that it believes unnecessary.)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XQ));
-#if !defined(RAG_PIPE_EXP) || !(RAG_PIPE_EXP & 8)
         __builtin_amdgcn_s_barrier();
-#endif
         xcur = xcur + 1 == NSX ? 0 : xcur + 1;
         qcur ^= 1;
         read_frags(xcur, qcur, 0, fa_x, fa_q);  // past the last stage: filler data, never multiplied
         __builtin_amdgcn_sched_barrier(0);
-        multiply(fb_x, fb_q);
+        multiply(fb_x, fb_q, [&] { q_ld(0); }, [&] { q_ld(1); });
         __builtin_amdgcn_sched_barrier(0);
-#endif
         if (ks == nk - 1) {
             // fa is in flight: let it land before compiler-scheduled code (spills included) runs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            const bool partial = row0 + BM > n;
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int tile_off = wm * BMW + 32 * t;
-                const long long rowbase = row0 + tile_off;
-                float xn[16];
-                if (METRIC == RAG_METRIC_L2) {
-                    // this lane's 16 rows: four runs of four (the LDS holds nothing but the rings)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const long long row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        xn[r] = row < n ? xnorm[row] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    float key[16];
-                    bool any = false;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        float v = acc[t][u][r];
-                        if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn[r]) - qn[u];
-                        key[r] = v;
-                        bool ok = v >= thr[u];
-                        if (partial) ok = ok && (rowbase + ro < n);
-                        any = any || ok;
-                    }
-                    if (__ballot(any) != 0ULL && my_q[u] < nq) {
-                        // rare: append every passing row of this lane's query to its buffer
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            if (key[r] >= thr[u] && rowbase + ro < n) {
-                                const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
-                                if (slot < (unsigned int)cap) {
-                                    const long long o = (long long)my_q[u] * cap + slot;
-                                    cand_key[o] = key[r];
-                                    cand_id[o] = (int)(rowbase + ro);
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-                }
-            }
+            epilogue(row0);
         }
         if (++ks == nk) {
             ks = 0;
-            row0 += (long long)S * tile_rows;
+            row0 += tile_stride;
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
 
 inline size_t pipe_smem_need() { return (size_t)5 * 256 * 128; }  // all of the CU's 160 KiB
+
+// words of the tiled query image for `col_tiles` query tiles of rows of ld words
+inline long long pipe_tiled_words(int col_tiles, int ld) { return (long long)col_tiles * (ld / 32) * 256 * 32; }
+
+inline int pipe_tile_queries(const float* Qw, int nq, int ld, int col_tiles, float* out, hipStream_t st) {
+    const long long slots = pipe_tiled_words(col_tiles, ld) / 4;
+    tile_queries_kernel<32><<<(unsigned)((slots + 255) / 256), 256, 0, st>>>(reinterpret_cast<const f32x4*>(Qw), nq, ld, ld / 32,
+                                                                         slots, reinterpret_cast<f32x4*>(out));
+    RAG_HIP(hipGetLastError());
+    return RAG_OK;
+}
 
 }  // namespace mfma
 }  // namespace rag
