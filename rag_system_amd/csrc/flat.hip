@@ -674,6 +674,7 @@ struct rag_flat {
     float* ws_cvt = nullptr; int64_t ws_cvt_cap = 0;   // fp32 staging for bfloat16 conversion
     unsigned short* ws_qb = nullptr; int64_t ws_qb_cap = 0;  // bfloat16 queries (MFMA operand)
     float* ws_qt = nullptr; int64_t ws_qt_cap = 0;           // queries as block shape 10's LDS image
+    unsigned int* ws_ticket = nullptr;                        // arrival counter of the stream kernel's fused merge (zero between launches)
     std::vector<float> staged;  // host rows not yet flushed (d floats each)
     // search workspace (HBM)
     float* ws_q = nullptr;   int64_t ws_q_cap = 0;     // padded queries
@@ -1114,15 +1115,26 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             snprintf(h->last_kernel, sizeof h->last_kernel, "%s list G%d RG%d KS%d NB%d blocks%d",
                      stream ? "stream" : "tile", stream ? sp.G : 0, stream ? sp.RG : 0, stream ? sp.KS : plan.KS,
                      stream ? sp.NB : plan.NS, stream ? sp.blocks : plan.nlists);
+            // 1-2 queries: the stream kernel's last block merges the block lists itself (one launch per search)
+            const bool fuse = stream && stream_can_fuse(sp, nq, k);
+            if (fuse && !h->ws_ticket) {
+                RAG_HIP(hipMalloc(&h->ws_ticket, 256));
+                RAG_HIP(hipMemsetAsync(h->ws_ticket, 0, 256, st));
+            }
             if (stream)
                 rc = stream_launch(sp, h->x, (long long)n, dch, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
-                                   h->ws_qn, st);
+                                   h->ws_qn, st, nullptr, nullptr, nullptr, fuse ? h->ws_ticket : nullptr,
+                                   fuse ? D_dev : nullptr, fuse ? I_dev : nullptr, (long long)id_base);
             else
                 rc = mfma_launch(plan, Xw, (long long)n, ldw, Qw, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
                                  h->ws_qn, h->zero16, st);
             if (rc) return rc;
             rc = prof.end(st);
             if (rc) return rc;
+            if (fuse) {
+                strncat(h->last_kernel, " fused-merge", sizeof h->last_kernel - strlen(h->last_kernel) - 1);
+                return RAG_OK;
+            }
             mf<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, stream ? sp.nlists : plan.nlists, k, D_dev,
                                                        I_dev, (long long)id_base, k, 0, nullptr);
             RAG_HIP(hipGetLastError());
@@ -1427,6 +1439,7 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_q);
         (void)hipFree(h->ws_qb);
         (void)hipFree(h->ws_qt);
+        (void)hipFree(h->ws_ticket);
         (void)hipFree(h->ws_cvt);
         (void)hipFree(h->ws_key);
         (void)hipFree(h->ws_id);

@@ -28,7 +28,11 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
 // xnorm / qnorm only for L2.
 int stream_launch(const StreamPlan& p, const void* X, long long n, int dch, const void* Q, int nq, int k, int metric,
                   float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st,
-                  const int* run_flag = nullptr, const float* thr_q = nullptr, unsigned int* counts = nullptr);
+                  const int* run_flag = nullptr, const float* thr_q = nullptr, unsigned int* counts = nullptr,
+                  unsigned int* ticket = nullptr, float* D = nullptr, long long* I = nullptr, long long id_base = 0);
+// List mode with 1-2 queries and k <= 16: with D / I (nq x k, device-writable) and a zeroed ticket word the block that
+// finishes last merges the per-block lists itself and writes the final result (no flat_merge_kernel launch).
+bool stream_can_fuse(const StreamPlan& p, long long nq, int k);
 
 // ---- flat_wide.hip: 9..64 queries per pass, 16x16 MFMA fed from registers, sample + filter passes only
 struct WidePlan {

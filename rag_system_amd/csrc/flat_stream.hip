@@ -1,9 +1,9 @@
 // flat_stream.hip -- exact top-k of a small query batch (nq <= 16) over a row-major matrix, rows
 // streamed from HBM straight into MFMA operands (no LDS staging of the matrix).
 //
-// Replaces, for 3..16 queries per call, the same reference loop as flat.hip:
-// vector_storage.py:257-271 (faiss IndexFlat.search) / :159-195 (Python fallback), one call per
-// query in the reference; SURVEY.md section 8 row (a), batched by search_engine.search_faiss_batch.
+// Replaces, for 1..16 queries per call, the same reference call as flat.hip: index.search(q, k),
+// vector_storage.py:196 (faiss IndexFlatIP built at :79 / :146 / :151), one call per query in the
+// reference; SURVEY.md section 8 row (a3), batched by search_engine.search_faiss_batch.
 //
 // Why a third kernel: with <= 16 queries every matrix element is used by exactly one matrix
 // instruction, so the LDS tile ring of flat_mfma_kernel.h only adds latency (its load, LDS and MFMA
@@ -89,6 +89,169 @@ __device__ __forceinline__ void fold_slices(float (&v)[N], int lane) {
     }
 }
 
+// ---- fused merge of the per-block lists (1-2 queries, k <= 16, <= 512 blocks): the block that finishes
+// LAST merges cand[q][0..nlists)[k] and writes D / I itself -- the same result as flat_merge_kernel
+// (flat.hip), bit for bit, without a second launch (a launch gap of ~6 us plus ~12 us of a 1024-thread
+// kernel behind a 2.1 ms pass).  Hand-off: every list entry is stored write-through (sc1: relaxed
+// agent-scope atomic stores, so no block needs a release fence), every storing wave drains its stores,
+// the block's barrier, one lane draws a ticket; the last arriver makes ONE agent-scope acquire and reads
+// the lists with plain loads.
+// The merge itself stays in registers and LDS: thread t loads the whole lists t and t + 256 in ONE
+// round trip (2k independent loads in flight), the k-th largest head T of the first 64 lists bounds the
+// result from below (k entries are >= T) and is found by rank counting over those heads in LDS (no
+// sorting network, two barriers); the entries >= T -- prefixes of the lists whose head is >= T, a few
+// times k of them -- are appended to an LDS buffer and placed by rank counting again.  More than FUSE_CAP such entries
+// (long tie runs): an exact k-way merge over the registers instead, one block-wide maximum per output.
+constexpr int FUSE_LPT = 2;                       // lists per thread
+constexpr int FUSE_MAX_LISTS = FUSE_LPT * ST_THREADS;
+constexpr int FUSE_MAX_K = 16;
+constexpr int FUSE_CAP = 512;
+constexpr size_t FUSE_SMEM = FUSE_MAX_LISTS * 4 + FUSE_CAP * 8 + 64;
+
+__device__ __forceinline__ unsigned long long fuse_pack(float key, int id) {
+    unsigned int u = __float_as_uint(key);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)id);
+}
+
+template <int METRIC>
+__device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const float* cand_key, const int* cand_id,
+                                                   int nlists, int nq, int k, float* __restrict__ D,
+                                                   long long* __restrict__ I, long long id_base) {
+    float* hv = reinterpret_cast<float*>(smem);                                                       // [FUSE_MAX_LISTS]
+    unsigned long long* sv = reinterpret_cast<unsigned long long*>(smem + FUSE_MAX_LISTS * 4);        // [FUSE_CAP]
+    unsigned long long* smax = reinterpret_cast<unsigned long long*>(smem + FUSE_MAX_LISTS * 4 + FUSE_CAP * 8);
+    int* n_cand = reinterpret_cast<int*>(smax + 1);
+    float* T_s = reinterpret_cast<float*>(smax + 2);
+    const int tid = threadIdx.x;
+    auto emit = [&](int q, int p, unsigned long long c) {
+        const long long o = (long long)q * k + p;
+        if (c != 0ULL) {
+            unsigned int u = (unsigned int)(c >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+            const float key = __uint_as_float(u);
+            D[o] = METRIC == RAG_METRIC_IP ? key : -key;
+            I[o] = id_base + (long long)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFULL));
+        } else {
+            D[o] = METRIC == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX;
+            I[o] = -1LL;
+        }
+    };
+    const int N4 = (nlists + 3) & ~3;
+    for (int q = 0; q < nq; ++q) {
+        const float* ck = cand_key + (long long)q * nlists * k;
+        const int* ci = cand_id + (long long)q * nlists * k;
+        // this thread's lists, whole, in one round trip; entries past k and lists past nlists are padding
+        float key[FUSE_LPT][FUSE_MAX_K];
+        int id[FUSE_LPT][FUSE_MAX_K];
+#pragma unroll
+        for (int u = 0; u < FUSE_LPT; ++u) {
+            const int l = tid + u * ST_THREADS;
+#pragma unroll
+            for (int e = 0; e < FUSE_MAX_K; ++e) {
+                key[u][e] = -FLT_MAX;
+                id[u][e] = IdPad<int>::v();
+                if (l < nlists && e < k) {
+                    key[u][e] = ck[(long long)l * k + e];
+                    id[u][e] = ci[(long long)l * k + e];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FUSE_LPT; ++u) {
+            const int l = tid + u * ST_THREADS;
+            if (l < N4) hv[l] = key[u][0];
+        }
+#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 2
+        return;
+#endif
+        if (tid == 0) {
+            *n_cand = 0;
+            *T_s = -FLT_MAX;  // fewer than k lists: everything is a candidate
+        }
+        __syncthreads();
+        // T: the k-th largest head among the FIRST 64 lists (rank counting by one wave, 64 LDS broadcasts).
+        // Any k entries bound the result from below; a quarter of the heads instead of all of them makes T
+        // a little lower and the candidate set a few times k larger, and saves the other 3/4 of a loop that
+        // one thread per list walks alone (all heads: 18 us of a 22 us tail; this way ~1 us).
+        const int ns = nlists < 64 ? nlists : 64;
+        if (tid < ns) {
+            const float h = key[0][0];
+            int rank = 0;
+            for (int j0 = 0; j0 < ns; j0 += 4) {
+                const f32x4 h4 = *reinterpret_cast<const f32x4*>(hv + j0);  // same address in every lane: a broadcast
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rank += (j0 + e < ns && (h4[e] > h || (h4[e] == h && j0 + e < tid))) ? 1 : 0;
+            }
+            if (rank == k - 1) *T_s = h;
+        }
+        __syncthreads();
+        const float T = *T_s;
+#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 3
+        return;
+#endif
+#pragma unroll
+        for (int u = 0; u < FUSE_LPT; ++u) {
+            // sorted: the entries >= T are a prefix; ONE counter update per list that has any
+            int c = 0;
+            bool more = true;
+#pragma unroll
+            for (int e = 0; e < FUSE_MAX_K; ++e) {
+                more = more && key[u][e] >= T && id[u][e] != IdPad<int>::v();
+                c += more ? 1 : 0;
+            }
+            if (c > 0) {
+                const int slot = atomicAdd(n_cand, c);
+#pragma unroll
+                for (int e = 0; e < FUSE_MAX_K; ++e)
+                    if (e < c && slot + e < FUSE_CAP) sv[slot + e] = fuse_pack(key[u][e], id[u][e]);
+            }
+        }
+        __syncthreads();
+        const int cnt = *n_cand;
+#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 4
+        return;
+#endif
+        if (cnt <= FUSE_CAP) {  // uniform
+            // place by rank: the composites are distinct (ids are), so the ranks are a permutation
+            for (int i = tid; i < cnt; i += ST_THREADS) {
+                const unsigned long long c = sv[i];
+                int r = 0;
+                for (int j = 0; j < cnt; ++j) r += sv[j] > c ? 1 : 0;
+                if (r < k) emit(q, r, c);
+            }
+            for (int p = cnt + tid; p < k; p += ST_THREADS) emit(q, p, 0ULL);
+            __syncthreads();  // sv / hv are reused by the next query
+            continue;
+        }
+        // long tie runs: exact k-way merge over the registers
+        int pos[FUSE_LPT];
+#pragma unroll
+        for (int u = 0; u < FUSE_LPT; ++u) pos[u] = 0;
+        for (int p = 0; p < k; ++p) {
+            if (tid == 0) *smax = 0ULL;
+            __syncthreads();
+            unsigned long long cur[FUSE_LPT], best = 0ULL;
+#pragma unroll
+            for (int u = 0; u < FUSE_LPT; ++u) {
+                cur[u] = 0ULL;
+#pragma unroll
+                for (int e = 0; e < FUSE_MAX_K; ++e)
+                    if (e == pos[u] && id[u][e] != IdPad<int>::v()) cur[u] = fuse_pack(key[u][e], id[u][e]);
+                best = cur[u] > best ? cur[u] : best;
+            }
+            if (best != 0ULL) atomicMax(smax, best);
+            __syncthreads();
+            const unsigned long long w = *smax;
+            if (tid == 0) emit(q, p, w);
+#pragma unroll
+            for (int u = 0; u < FUSE_LPT; ++u)
+                if (w != 0ULL && cur[u] == w) ++pos[u];  // ids are unique: exactly one list of one thread
+            __syncthreads();
+        }
+    }
+}
+
 // n >= 4*RG (the host plans the tile kernel for smaller shards): the last, partial wave tile is
 // the window [n - 4*RG, n) with the rows below the tile's own first row masked out.
 #ifndef RAG_STREAM_MINB
@@ -99,7 +262,8 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
     const u32x4* __restrict__ X, long long n, int dch, const u32x4* __restrict__ Q, int nq, int k,
     float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
     const float* __restrict__ qnorm, long long tile_step, const int* __restrict__ run_flag,
-    const float* __restrict__ thr_q, unsigned int* __restrict__ counts, int cap) {
+    const float* __restrict__ thr_q, unsigned int* __restrict__ counts, int cap, unsigned int* __restrict__ ticket,
+    float* __restrict__ D, long long* __restrict__ I, long long id_base) {
     if (run_flag != nullptr && *run_flag == 0) return;  // uniform, before any barrier
     extern __shared__ __align__(16) unsigned char smem_raw[];
     u32x4* q_lds = reinterpret_cast<u32x4*>(smem_raw);
@@ -356,12 +520,43 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
             for (int s = 0; s < KS; ++s) {
                 const int p = s * 64 + lane;
                 if (p < k) {
-                    cand_key[base + p] = tk[q].key[s];
-                    cand_id[base + p] = tk[q].id[s];
+                    if (D != nullptr) {  // read by this launch's last block: write-through (sc1) stores
+                        __hip_atomic_store(cand_key + base + p, tk[q].key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(cand_id + base + p, tk[q].id[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        cand_key[base + p] = tk[q].key[s];
+                        cand_id[base + p] = tk[q].id[s];
+                    }
                 }
             }
         }
     }
+    if constexpr (G != 1 || KS != 1) return;  // the fused merge exists for 1-2 queries with k <= 16 only
+    if (D == nullptr) return;  // uniform: the caller merges the lists with flat_merge_kernel
+    // ---- fused merge: every storing wave drains its (write-through) stores, the block's barrier, then ONE
+    // lane draws the ticket; the last arriver acquires and reads every block's lists
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* last = reinterpret_cast<int*>(smem_raw + FUSE_SMEM - 16);
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool is_last = t == gridDim.x - 1;
+        if (is_last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            // plain loads behind ONE acquire: reading the lists with sc1 loads instead (no fence) took 18 us --
+            // thousands of uncached 4-byte reads of a 25 KB region, against 200 cache lines this way
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *last = is_last ? 1 : 0;
+    }
+    __syncthreads();
+    if (*last == 0) return;
+    __syncthreads();  // *last is read by everyone before the merge reuses the LDS
+#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 1
+    return;
+#endif
+    stream_fused_merge<METRIC>(smem_raw, cand_key, cand_id, (int)gridDim.x, nq, k, D, I, id_base);
 }
 
 struct Args {
@@ -375,6 +570,10 @@ struct Args {
     const float* thr_q;
     unsigned int* counts;
     hipStream_t st;
+    unsigned int* ticket;  // fused merge (list mode, D != nullptr): zero between launches
+    float* D;
+    long long* I;
+    long long id_base;
 };
 
 template <int G, int RG, int KS, bool BF, bool FILT, int NB>
@@ -386,7 +585,8 @@ int launch_nb(const StreamPlan& p, const Args& a) {
                                     (int)p.smem));
     fn<<<(unsigned)p.blocks, ST_THREADS, p.smem, a.st>>>(
         reinterpret_cast<const u32x4*>(a.X), a.n, a.dch, reinterpret_cast<const u32x4*>(a.Q), a.nq, a.k, a.cand_key,
-        a.cand_id, a.xnorm, a.qnorm, (long long)p.tile_step, a.run_flag, a.thr_q, a.counts, p.cap);
+        a.cand_id, a.xnorm, a.qnorm, (long long)p.tile_step, a.run_flag, a.thr_q, a.counts, p.cap, a.ticket, a.D, a.I,
+        a.id_base);
     RAG_HIP(hipGetLastError());
     return RAG_OK;
 }
@@ -457,6 +657,7 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     const size_t qbytes = (size_t)p->G * dchp * 64;
     const size_t mbytes = filt ? 0 : (size_t)ST_WAVES * 4 * p->G * p->KS * 64 * 8;
     p->smem = std::max(qbytes, mbytes);
+    if (!filt && nq <= 2 && k <= FUSE_MAX_K) p->smem = std::max(p->smem, FUSE_SMEM);  // room for the fused merge of the block lists
     if (p->smem > 64 * 1024) return false;  // long rows: the tile kernel streams its queries instead
     const long long TR = 4 * p->RG;
     const long long ntiles = ((n + TR - 1) / TR + p->tile_step - 1) / p->tile_step;
@@ -472,16 +673,27 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     return true;
 }
 
+bool stream_can_fuse(const StreamPlan& p, long long nq, int k) {
+    return !p.filt && nq <= 2 && k <= FUSE_MAX_K && p.blocks <= FUSE_MAX_LISTS && p.smem >= FUSE_SMEM &&
+           options().stream_fuse >= 0;
+}
+
 int stream_launch(const StreamPlan& p, const void* X, long long n, int dch, const void* Q, int nq, int k, int metric,
                   float* cand_key, int* cand_id, const float* xnorm, const float* qnorm, hipStream_t st,
-                  const int* run_flag, const float* thr_q, unsigned int* counts) {
+                  const int* run_flag, const float* thr_q, unsigned int* counts, unsigned int* ticket, float* D,
+                  long long* I, long long id_base) {
+    if (D != nullptr && (p.filt || nq > 2 || k > FUSE_MAX_K || p.blocks > FUSE_MAX_LISTS || ticket == nullptr ||
+                         I == nullptr || p.smem < FUSE_SMEM || run_flag != nullptr))
+        return fail(RAG_ERR_INVALID_ARG, "stream kernel: the fused merge serves list mode with 1-2 queries, k <= %d and <= %d blocks",
+                    FUSE_MAX_K, FUSE_MAX_LISTS);
     if (nq < 1 || nq > 4 * p.G) return fail(RAG_ERR_INVALID_ARG, "stream kernel: nq=%d beyond the planned %d", nq, 4 * p.G);
     if (!p.filt && (k < 1 || k > 64 * p.KS)) return fail(RAG_ERR_INVALID_ARG, "stream kernel: k=%d beyond %d", k, 64 * p.KS);
     if (p.filt && (thr_q == nullptr || counts == nullptr || p.cap < 1))
         return fail(RAG_ERR_INVALID_ARG, "stream kernel: filter mode needs thresholds, counters and a capacity");
     if (metric == RAG_METRIC_L2 && (xnorm == nullptr || qnorm == nullptr))
         return fail(RAG_ERR_INVALID_ARG, "stream kernel: L2 needs row and query norms");
-    const Args a{X, Q, n, dch, nq, k, metric, cand_key, cand_id, xnorm, qnorm, run_flag, thr_q, counts, st};
+    const Args a{X, Q, n, dch, nq, k, metric, cand_key, cand_id, xnorm, qnorm, run_flag, thr_q, counts, st,
+                 ticket, D, I, id_base};
     return p.bf16 ? launch_g<true>(p, a) : launch_g<false>(p, a);
 }
 

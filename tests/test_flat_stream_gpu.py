@@ -214,3 +214,66 @@ def test_default_thresholds_on_a_large_shard(engine):
         finally:
             _opts(lib, stream_max_nq=0)
         assert np.array_equal(I, I2), (nq, k)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_fused_merge_equals_merge_kernel(engine, metric, storage):
+    """1-2 queries, k <= 16, in list mode: the stream kernel's last block merges the per-block lists
+    itself (stream_fused_merge); larger k keeps the merge kernel.  Bit-identical to the separate flat_merge_kernel launch (option
+    stream_fuse = -1) and exact against the oracle: few and many blocks, k from 1 to 128, k larger
+    than the number of rows and of lists (padding), a non-zero id base, and tie runs long enough to
+    take the k-way merge path (all-equal rows; 700 copies of the best row)."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(4242 + metric)
+    rnd = od.bf16_round if storage == "bf16" else (lambda a: a)
+    cases = []
+    for n, d in [(16, 64), (150, 384), (5_000, 96), (70_001, 64), (300_000, 32)]:
+        X = _rand_unit(rng, n, d)
+        cases.append(("random", X))
+    Xe = np.tile(_rand_unit(rng, 1, 48), (40_000, 1))          # every score equal: ties decide everything
+    cases.append(("all_equal", Xe))
+    Xt = _rand_unit(rng, 60_000, 48)
+    Xt[rng.choice(60_000, 700, replace=False)] = Xt[5]          # 700 exact copies of one row
+    cases.append(("ties_at_top", Xt))
+    try:
+        for name, X in cases:
+            n, d = X.shape
+            idx = faiss.IndexFlat(d, metric, storage=storage)
+            idx.add(X)
+            Xr = rnd(X)
+            for nq, k in [(1, 1), (1, 10), (2, 10), (2, 16), (1, 3), (1, 64), (2, 100), (1, 128), (2, 17)]:
+                Q = _rand_unit(rng, nq, d)
+                Q[0] = X[5]
+                Qr = rnd(Q)
+                _opts(lib, stream_fuse=0)
+                D, I = idx.search(Q, k)
+                fused = "fused-merge" in idx._b.last_kernel()
+                _opts(lib, stream_fuse=-1)
+                D0, I0 = idx.search(Q, k)
+                assert "fused-merge" not in idx._b.last_kernel()
+                assert np.array_equal(I, I0) and np.array_equal(D, D0), (name, n, d, nq, k)
+                assert fused == (n >= 16 and k <= 16), (name, n, nq, k, idx._b.last_kernel())
+                _, Ir, D64 = od.flat_search(Xr, Qr, k, metric)
+                od.check_topk(D, I, D64, Ir, RTOL, ATOL if metric == 0 else 4e-6, _scorer(Xr, Qr, metric))
+                if name != "random":
+                    assert np.array_equal(I, Ir), (name, nq, k)   # exact ties: lowest ids first, like the oracle
+        # id base through the device entry point
+        import torch
+        X = _rand_unit(rng, 20_000, 64)
+        idx = faiss.IndexFlat(64, metric, storage=storage)
+        idx.add(X)
+        Q = _rand_unit(rng, 2, 64)
+        _opts(lib, stream_fuse=0)
+        D, I = idx.search(Q, 10)
+        qd = torch.from_numpy(Q).cuda()
+        Dd = torch.empty((2, 10), dtype=torch.float32, device="cuda")
+        Id = torch.empty((2, 10), dtype=torch.int64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        idx._b.search_dev(2, qd.data_ptr(), 10, Dd.data_ptr(), Id.data_ptr(), 7_000_000_000, st)
+        torch.cuda.synchronize()
+        assert "fused-merge" in idx._b.last_kernel()
+        assert np.array_equal(Id.cpu().numpy(), I + 7_000_000_000) and np.array_equal(Dd.cpu().numpy(), D)
+    finally:
+        _opts(lib, stream_fuse=0)
