@@ -160,7 +160,7 @@ int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double
  * "scan_rows", "mfma_min_nq", "mfma_shape" (1..9), "mfma_bpc", "mfma_stages" (2..3),
  * "mfma_filter_k", "mfma_filter_min_rows", "mfma_filter_step" (when the batch kernels use thresholds +
  * append buffers, and how densely the rows are sampled for the thresholds),
- * "stream_max_nq" (-1: never), "stream_rg", "stream_bpc", "stream_nb", "stream_fuse" (-1: separate merge launch) (register-fed kernel for up to 16 queries),
+ * "stream_max_nq" (-1: never), "stream_rg", "stream_bpc", "stream_nb", "stream_fuse" (-1: separate merge launch), "mfma_pipe_sample" (-1: list-mode sample pass) (register-fed kernel for up to 16 queries),
  * "wide_max_nq" (-1: never), "wide_min_nq", "wide_wpb" (register-fed kernel for 9..64 queries),
  * "sparse_topk_lists" (1: BM25 / TF-IDF top-k by the list kernels only, no threshold path),
  * "sparse_fused" (0: BM25 / TF-IDF scoring by one launch per query term instead of the fused kernel).

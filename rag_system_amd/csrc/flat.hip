@@ -1077,6 +1077,12 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         if (stream && filter) need = std::max<int64_t>(need, nq * (int64_t)sps.nlists);
         if (wide && filter) need = std::max<int64_t>(need, nq * (int64_t)wp.wpad);
         if (filter) need = std::max<int64_t>(need, std::max<int64_t>(nq * ps.nlists * j, nq * (int64_t)cap));
+        // tile-kernel filter flow with the pipelined kernel: its sample mode leaves two values per visited row
+        // tile and query, of which kth_largest_kernel sorts up to 4096
+        const long long pipe_ntv = ((n + 255) / 256 + FILTER_STEP - 1) / FILTER_STEP;
+        const bool pipe_sample = filter && !wide && !stream && mfma_tiled_query_words(pf, ld * h->esz / 4) > 0 &&
+                                 2 * pipe_ntv <= 4096 && opt.mfma_pipe_sample >= 0;
+        if (pipe_sample) need = std::max<int64_t>(need, nq * 2 * pipe_ntv);
         rc = grow(h->ws_key, h->ws_key_cap, need);
         if (rc) return rc;
         rc = grow(h->ws_id, h->ws_id_cap, need);
@@ -1158,6 +1164,18 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                                h->ws_qn, st);
             if (rc) return rc;
             kth_largest_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, sps.nlists, sps.nlists, j, h->ws_thr);
+        } else if (pipe_sample) {
+            // the pipelined kernel's own sample mode: the best score per wave tile and query, no lists
+            rc = mfma_tile_queries(pf, Qw, (int)nq, ldw, h->ws_qt, st);
+            if (rc) return rc;
+            MfmaPlan psm = pf;
+            psm.tile_step = FILTER_STEP;
+            psm.S = (int)std::min<long long>(pf.S, pipe_ntv);
+            psm.cap = (int)(2 * pipe_ntv);
+            rc = mfma_launch(psm, Xw, (long long)n, ldw, h->ws_qt, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,
+                             h->ws_qn, h->zero16, st);
+            if (rc) return rc;
+            kth_largest_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, psm.cap, psm.cap, j, h->ws_thr);
         } else {
             rc = mfma_launch(ps, Xw, (long long)n, ldw, Qw, (int)nq, j, h->metric, h->ws_key, h->ws_id, h->xnorm,
                              h->ws_qn, h->zero16, st);
@@ -1182,8 +1200,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         else {
             const float* Qf = Qw;
             if (mfma_tiled_query_words(pf, ldw) > 0) {  // the pipelined kernel reads a tiled image of the queries
-                rc = mfma_tile_queries(pf, Qw, (int)nq, ldw, h->ws_qt, st);
-                if (rc) return rc;
+                if (!pipe_sample) {                      // (already made for its sample pass)
+                    rc = mfma_tile_queries(pf, Qw, (int)nq, ldw, h->ws_qt, st);
+                    if (rc) return rc;
+                }
                 Qf = h->ws_qt;
             }
             rc = mfma_launch(pf, Xw, (long long)n, ldw, Qf, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm,

@@ -528,10 +528,13 @@ constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 namespace rag {
 namespace mfma {
 
+// thr_q == nullptr: the sample pass (tile_step > 1; cand_key receives p.cap values per query).
 template <bool BF>
 int launch_pipe(const MfmaPlan& p, const Args& a) {
     const size_t smem = pipe_smem_need();
-    auto fn = a.metric == RAG_METRIC_IP ? flat_pipe_kernel<RAG_METRIC_IP, BF> : flat_pipe_kernel<RAG_METRIC_L2, BF>;
+    const bool sample = a.thr_q == nullptr;
+    auto fn = a.metric == RAG_METRIC_IP ? (sample ? flat_pipe_kernel<RAG_METRIC_IP, BF, true> : flat_pipe_kernel<RAG_METRIC_IP, BF, false>)
+                                        : (sample ? flat_pipe_kernel<RAG_METRIC_L2, BF, true> : flat_pipe_kernel<RAG_METRIC_L2, BF, false>);
     RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     fn<<<(unsigned)(p.S * p.col_tiles), 512, smem, a.st>>>(a.X, a.n, a.ld, a.Qp, a.nq, p.S, p.col_tiles, a.cand_key,
                                                           a.cand_id, a.xnorm, a.qnorm, a.zero16, (long long)p.tile_step,

@@ -90,7 +90,15 @@ __device__ unsigned long long g_pipe_check[8];
 #define RAG_GLDS(ptr, dst, lo, nbytes, tag) glds16(ptr, dst)
 #endif
 
-template <int METRIC, bool BF>
+// SAMPLE = false: the filter pass (thr_q, counts, cand_*[q][cap]).
+// SAMPLE = true: the sample pass of the filter flow (flat.hip) -- only the row tiles t * tile_step are
+//   visited and no threshold exists yet; each wave leaves the BEST score of every query over its 128 rows
+//   of every visited tile in cand_key[q * cap + 2 * (visited tile) + wm] (cap = values per query), and the
+//   j-th largest of a query's values is its threshold (kth_largest_kernel): j wave tiles hold a row that
+//   good, i.e. it is the j-th best sampled row unless two of the best j share a wave tile, which only
+//   lowers it.  No lists, no inserts: the pass costs what its tiles cost (it used to be the list-mode
+//   tile kernel, whose every list has to fill up first: 1.33 ms of C3's 17.2 for 1.6 % of the rows).
+template <int METRIC, bool BF, bool SAMPLE>
 __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     const float* __restrict__ X, long long n, int ld, const float* __restrict__ Qp, int nq, int S, int col_tiles,
     float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
@@ -142,7 +150,8 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         my_q[u] = q0 + BNW * wn + 32 * u + li;
-        thr[u] = my_q[u] < nq ? thr_q[my_q[u]] : FLT_MAX;
+        thr[u] = FLT_MAX;
+        if (!SAMPLE) thr[u] = my_q[u] < nq ? thr_q[my_q[u]] : FLT_MAX;
         qn[u] = 0.f;
         if (METRIC == RAG_METRIC_L2) qn[u] = my_q[u] < nq ? qnorm[my_q[u]] : 0.f;
         // the compiler waits for these two loads HERE, not with a vmcnt(0) in front of their first use in
@@ -307,6 +316,9 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     // query's threshold, passing rows appended through the query's counter, accumulators cleared.
     auto epilogue = [&](int row0) {
         const bool partial = row0 + BM > nrows;
+        float best[NT];  // SAMPLE: this lane's best score per query over the wave's 128 rows
+#pragma unroll
+        for (int u = 0; u < NT; ++u) best[u] = -FLT_MAX;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int tile_off = wm * BMW + 32 * t;
@@ -330,11 +342,12 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
                     float v = acc[t][u][r];
                     if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn[r]) - qn[u];
                     key[r] = v;
-                    bool ok = v >= thr[u];
+                    bool ok = SAMPLE || v >= thr[u];
                     if (partial) ok = ok && (rowbase + ro < nrows);
+                    if (SAMPLE) best[u] = ok ? fmaxf(best[u], v) : best[u];
                     any = any || ok;
                 }
-                if (__ballot(any) != 0ULL && my_q[u] < nq) {
+                if (!SAMPLE && __ballot(any) != 0ULL && my_q[u] < nq) {
                     // rare: append every passing row of this lane's query to its buffer
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -351,6 +364,15 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+            }
+        }
+        if (SAMPLE) {
+            // the other 16 rows of every 32-row tile live in lane ^ 32; visited tile number = row0 / tile_rows
+            const int slot = 2 * (row0 / tile_rows) + wm;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const float m = fmaxf(best[u], __shfl_xor(best[u], 32, 64));
+                if (lh == 0 && my_q[u] < nq) cand_key[(long long)my_q[u] * cap + slot] = m;
             }
         }
     };

@@ -76,6 +76,7 @@ class ShardedFlatSearcher:
         self.local_search = local_search
         self.merge = merge or _hip_merge
         self.stream = stream
+        self._stream_handle = None
         self.on_gpu = torch.device(device).type == "cuda"
         # one packed buffer per rank: nq*k int64 ids, then nq*k float32 scores (padded to 8 bytes)
         m = nq * k
@@ -118,14 +119,20 @@ class ShardedFlatSearcher:
     def _handle(self):
         if not self.on_gpu:
             return 0
-        s = self.stream if self.stream is not None else self._torch.cuda.current_stream()
-        return s.cuda_stream
+        if self.stream is not None:
+            if self._stream_handle is None:
+                self._stream_handle = self.stream.cuda_stream
+            return self._stream_handle
+        return self._torch.cuda.current_stream().cuda_stream
 
     def search(self, q):
         """q: (nq, d) tensor on the searcher's device.  Returns (D_out, I_out) tensors, complete when
         the searcher's stream reaches this point (GPU) / on return (CPU)."""
         torch = self._torch
-        ctx = torch.cuda.stream(self.stream) if (self.on_gpu and self.stream is not None) else contextlib.nullcontext()
+        # one rank and no stage timing: nothing of torch's is enqueued here (local_search gets the stream's
+        # handle explicitly), so the current-stream switch, a few microseconds per call, is skipped
+        need_ctx = self.on_gpu and self.stream is not None and (self.world > 1 or self.stage_events)
+        ctx = torch.cuda.stream(self.stream) if need_ctx else contextlib.nullcontext()
         with ctx:
             st = self._handle()
             ev = self.stage_events
