@@ -463,7 +463,7 @@ def c5_leg(n_queries=40):
             "stage_ms": {s: tsum[s] / nq * 1e3 for s in STAGES},
             "sparse_roofline": {s: {"bound": "hbm", "achieved": sb[s] / tsum[s] / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": sb[s] / tsum[s] / 1e9 / HBM_PEAK_GBS,
-                                    "note": "algorithmic bytes / wall clock of the whole C-ABI call"}
+                                    "note": "algorithmic bytes / wall clock of the whole C-ABI call (scoring launch + selection launch, results in pinned memory, one synchronise); kernel-time figures: DESIGN.md 4.3"}
                                 for s in ("bm25", "tfidf")},
             "parity_checked_queries": checked}
 

@@ -103,7 +103,7 @@ def main():
             s: {"bound": "hbm", "achieved": sparse_bytes[s] / tsum[s] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": sparse_bytes[s] / tsum[s] / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_query": sparse_bytes[s] / nq,
-                "note": "wall clock of the whole C-ABI call (launch per query term + top-k + D2H + sync)"}
+                "note": "algorithmic bytes / wall clock of the whole C-ABI call (scoring launch + selection launch, results in pinned memory, one synchronise); kernel-time figures: DESIGN.md 4.3"}
             for s in ("bm25", "tfidf")},
         "parity": {"queries_checked": checked, "bm25": "ids and float64 scores bit-exact", "tfidf": "ids exact, scores 1e-12",
                    "ranks": "exact", "dense": "ids exact", "rrf": "identical to RRF over the full rankings",
