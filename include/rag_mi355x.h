@@ -178,6 +178,17 @@ int rag_set_option(const char* name, int64_t value);
  * (TfidfVectorizer.fit_transform, vector_storage.py:216-217). */
 int rag_csc_create(int64_t n_terms, int64_t n_rows, const int64_t* indptr,
                    const int32_t* row, const double* val, rag_csc_t** out);
+/* The postings of a tokenised corpus, built on the device (sort + segment) instead of the
+ * per-document dictionary loops of rank_bm25's BM25Okapi.__init__ (called at
+ * vector_storage.py:170,305 on the corpus tokenised at :162).  Document i =
+ * words[doc_indptr[i] .. doc_indptr[i+1]), words in [0, n_words).  Outputs (host, caller-
+ * allocated): *n_terms distinct words; term_word[t] (capacity n_words) = the word of term t,
+ * terms numbered by first appearance (the order of rank_bm25's dictionaries); indptr
+ * (capacity n_words + 1); row / tf (capacity n_tokens, *nnz used): the postings of term t,
+ * ascending by document, tf = term frequency.  Feed them to rag_csc_create. */
+int rag_postings_build(int64_t n_docs, const int64_t* doc_indptr, int64_t n_tokens, const int32_t* words,
+                       int64_t n_words, int64_t* n_terms, int32_t* term_word, int64_t* indptr, int32_t* row,
+                       double* tf, int64_t* nnz);
 void rag_csc_free(rag_csc_t* h);
 /* BM25Okapi parameters: per-term idf (epsilon floor already applied), per-row
  * token count, avgdl, k1, b (rank_bm25 BM25Okapi.__init__/_calc_idf). */

@@ -74,6 +74,7 @@ SIGNATURES = {
     "rag_flat_timing": (C.c_int, [_p, _i64p, _f64p, _f64p]),
     "rag_set_option": (C.c_int, [C.c_char_p, _i64]),
     "rag_csc_create": (C.c_int, [_i64, _i64, _p, _p, _p, C.POINTER(_p)]),
+    "rag_postings_build": (C.c_int, [_i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "rag_csc_free": (None, [_p]),
     "rag_bm25_set": (C.c_int, [_p, _p, _p, C.c_double, C.c_double, C.c_double]),
     "rag_bm25_scores": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, _p, _p]),

@@ -4,9 +4,11 @@ Reference call sites: BM25Okapi(corpus, k1=, b=) vector_storage.py:170, BM25Okap
 :305 (library defaults k1=1.5, b=0.75, epsilon=0.25), bm25.get_scores(tokens) :178 followed by
 the full stable descending sort of :180.
 
-The index statistics (vocabulary, term frequencies, idf with the epsilon floor, avgdl) are
-built on the host exactly as rank_bm25 builds them; the postings are uploaded once as a
-term-major (CSC) matrix; get_scores / top_k run rag_bm25_scores (csrc/sparse.hip).
+The index statistics equal rank_bm25's: tokens are mapped to integer words on the host, the
+vocabulary order, term frequencies and document frequencies come from rag_postings_build
+(csrc/build.hip: sort + segment on the GPU), idf with the epsilon floor and avgdl are computed on
+the host in rank_bm25's order; the postings are uploaded once as a term-major (CSC) matrix;
+get_scores / top_k run rag_bm25_scores (csrc/sparse.hip).
 """
 import ctypes as C
 import math
@@ -107,6 +109,27 @@ def make_csc(n_terms, n_rows, indptr, rows, vals):
     return _csc_factory(n_terms, n_rows, indptr, rows, vals)
 
 
+def device_postings(doc_indptr, words, n_words):
+    """(term_word, indptr, rows, tf) of a corpus given as integer words (document i =
+    words[doc_indptr[i]:doc_indptr[i+1]], words in [0, n_words)), built on the GPU by
+    rag_postings_build (csrc/build.hip: sort + segment).  Terms are numbered by first appearance;
+    term_word[t] is the word of term t; the postings of a term ascend by document."""
+    lib = _lib.engine()
+    doc_indptr = np.ascontiguousarray(doc_indptr, dtype=np.int64)
+    words = np.ascontiguousarray(words, dtype=np.int32)
+    n_docs, n_tokens, n_words = len(doc_indptr) - 1, len(words), int(n_words)
+    n_terms, nnz = C.c_int64(0), C.c_int64(0)
+    term_word = np.empty(max(n_words, 1), dtype=np.int32)
+    indptr = np.empty(n_words + 1, dtype=np.int64)
+    rows = np.empty(max(n_tokens, 1), dtype=np.int32)
+    tf = np.empty(max(n_tokens, 1), dtype=np.float64)
+    _lib.check(lib.rag_postings_build(n_docs, _lib.ptr(doc_indptr), n_tokens, _lib.ptr(words), n_words,
+                                      C.byref(n_terms), _lib.ptr(term_word), _lib.ptr(indptr), _lib.ptr(rows),
+                                      _lib.ptr(tf), C.byref(nnz)), lib)
+    nt, nz = n_terms.value, nnz.value
+    return term_word[:nt], indptr[:nt + 1], rows[:nz].copy(), tf[:nz].copy()
+
+
 class BM25Okapi:
     """rank_bm25.BM25Okapi(corpus, tokenizer=None, k1=1.5, b=0.75, epsilon=0.25)."""
 
@@ -124,6 +147,28 @@ class BM25Okapi:
         self.doc_len = []
         self.idf = {}
         self._vocab = {}          # word -> term id, in first-appearance order (= nd order)
+        if _csc_factory is _HipCsc:
+            # device build: tokens -> integer words in one pass, postings by sort + segment
+            # on the GPU instead of a dictionary of frequencies per document
+            vocab, words, indptr = self._vocab, [], [0]
+            for document in corpus:
+                for word in document:
+                    t = vocab.get(word)
+                    if t is None:
+                        t = len(vocab)
+                        vocab[word] = t
+                    words.append(t)
+                indptr.append(len(words))
+            self.corpus_size = len(indptr) - 1
+            if self.corpus_size == 0:
+                raise ZeroDivisionError("division by zero")  # rank_bm25: num_doc / corpus_size
+            lens = np.diff(np.asarray(indptr, dtype=np.int64))
+            self.doc_len = lens.tolist()
+            self.avgdl = len(words) / self.corpus_size
+            term_word, p_indptr, rows, tf = device_postings(indptr, np.asarray(words, dtype=np.int32), len(vocab))
+            assert np.array_equal(term_word, np.arange(len(vocab)))   # words were numbered by first appearance
+            self._finish(np.diff(p_indptr), p_indptr, rows, tf)
+            return
         post_rows = []            # per term: list of doc ids (ascending)
         post_tf = []
         num_doc = 0
@@ -171,6 +216,14 @@ class BM25Okapi:
         lens = np.diff(doc_indptr)
         self.doc_len = lens.tolist()
         self.avgdl = int(lens.sum()) / n
+        if (_csc_factory is _HipCsc and len(doc_terms) > 0 and int(doc_terms.min()) >= 0
+                and int(doc_terms.max()) < (1 << 27)):
+            # device build: first-appearance vocabulary, (term, doc) pairs and frequencies by sort + segment
+            term_word, p_indptr, rows, tf = device_postings(doc_indptr, doc_terms.astype(np.int32), int(doc_terms.max()) + 1)
+            self._vocab = {int(w): t for t, w in enumerate(term_word.tolist())}
+            self.idf = {}
+            self._finish(np.diff(p_indptr), p_indptr, rows, tf)
+            return self
         doc_of = np.repeat(np.arange(n, dtype=np.int64), lens)
         # vocabulary in first-appearance order
         uniq, first_pos = np.unique(doc_terms, return_index=True)
