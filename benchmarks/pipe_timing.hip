@@ -4,7 +4,7 @@
 // read).  Not part of librag_mi355x.so.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DRAG_PIPE_EXP=n] -Iinclude -o benchmarks/pipe_timing[_n] \
 //       benchmarks/pipe_timing.hip rag_system_amd/csrc/lib.hip
-//   ./benchmarks/pipe_timing [nq=1024] [d=768] [n=10000000] [stages=4] [zeros=0] [spec=0]
+//   ./benchmarks/pipe_timing [nq=1024] [d=768] [n=10000000] [stages=4] [zeros=0]
 #include "../rag_system_amd/csrc/flat_mfma_kernel.h"
 
 #include <cstdlib>
@@ -33,7 +33,6 @@ int main(int argc, char** argv) {
     const long long n = argc > 3 ? atoll(argv[3]) : 10000000LL;
     const int stages = argc > 4 ? atoi(argv[4]) : 4;
     const bool zeros = argc > 5 ? atoi(argv[5]) != 0 : false;
-    const bool spec = argc > 6 ? atoi(argv[6]) != 0 : false;   // 1: flat_spec_kernel (loader waves, block shape 11)
     if (rag_init(0) != 0) { fprintf(stderr, "%s\n", rag_last_error()); return 1; }
     const int ldw = d / 2;
     unsigned int *X, *Q, *counts;
@@ -66,7 +65,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(a, st));
         const rag::mfma::Args args{(const float*)X, n, ldw, (const float*)Qt, nq, 100, 0, ck, ci, nullptr, nullptr, zero, st,
                                    nullptr, thr, counts};
-        if (spec ? rag::mfma::launch_spec<true>(p, args) : rag::mfma::launch_pipe<true>(p, args)) {
+        if (rag::mfma::launch_pipe<true>(p, args)) {
             fprintf(stderr, "%s\n", rag_last_error()); return 1;
         }
         CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));

@@ -87,16 +87,16 @@ bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p
     // flat_mfma_pipe.h (config C3: 17.x ms per batch against 19.1 for shape 4)
     if (nq > 128 && bf16 && ld_words > 0 && ld_words % 32 == 0) shape = 9;
     const long long force = options().mfma_shape;
-    if ((force >= 1 && force <= 4) || (force >= 7 && force <= 11)) shape = (int)force - 1;
+    if ((force >= 1 && force <= 4) || (force >= 7 && force <= 10)) shape = (int)force - 1;
     int NS = 3;
     if (options().mfma_stages >= 2 && options().mfma_stages <= 3) NS = (int)options().mfma_stages;
-    if (shape >= 9) {  // pipelined kernels: fixed rings (3 row stages, 2 query stages), whole 128-byte lines
+    if (shape == 9) {  // pipelined kernel: fixed rings (3 row stages, 2 query stages), whole 128-byte lines
         if (ld_words % 32 != 0) shape = 3;
         else NS = 3;
     }
     const Shape& sh = SHAPES[shape];
     int bpc = sh.bpc;
-    if (shape < 9)
+    if (shape != 9)
     while (mfma::smem_need(sh.WM, sh.WN, sh.MT, sh.NT, sh.BK, NS, 0) * bpc > 160 * 1024) {
         if (NS > 2) --NS;
         else if (bpc > 1) --bpc;
@@ -127,7 +127,7 @@ bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p
 int mfma_block_rows(const MfmaPlan& p) { return 32 * p.MT * p.WM; }
 
 long long mfma_tiled_query_words(const MfmaPlan& p, int ld_words) {
-    return p.shape >= 9 ? mfma::pipe_tiled_words(p.col_tiles, ld_words) : 0;
+    return p.shape == 9 ? mfma::pipe_tiled_words(p.col_tiles, ld_words) : 0;
 }
 int mfma_tile_queries(const MfmaPlan& p, const float* Qw, int nq, int ld_words, float* out, hipStream_t st) {
     return mfma::pipe_tile_queries(Qw, nq, ld_words, p.col_tiles, out, st);

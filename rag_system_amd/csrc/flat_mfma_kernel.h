@@ -515,8 +515,6 @@ constexpr Shape SHAPES[] = {
                           //    8 MFMAs instead of 9); measured equal to shape 4, kept as an option
     {2, 4, 4, 2, 32, 1},  // 10: the same tile with the software-pipelined K loop of flat_mfma_pipe.h
                           //    (filter mode only, rows of whole 128-byte lines)
-    {2, 4, 4, 2, 32, 1},  // 11: the same tile with four loader waves beside the eight compute waves
-                          //    (flat_mfma_spec.h; filter mode only)
 };
 constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
@@ -527,7 +525,6 @@ constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 }  // namespace mfma
 }  // namespace rag
 #include "flat_mfma_pipe.h"
-#include "flat_mfma_spec.h"
 namespace rag {
 namespace mfma {
 
@@ -540,20 +537,6 @@ int launch_pipe(const MfmaPlan& p, const Args& a) {
                                         : (sample ? flat_pipe_kernel<RAG_METRIC_L2, BF, true> : flat_pipe_kernel<RAG_METRIC_L2, BF, false>);
     RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     fn<<<(unsigned)(p.S * p.col_tiles), 512, smem, a.st>>>(a.X, a.n, a.ld, a.Qp, a.nq, p.S, p.col_tiles, a.cand_key,
-                                                          a.cand_id, a.xnorm, a.qnorm, a.zero16, (long long)p.tile_step,
-                                                          a.run_flag, a.thr_q, a.counts, p.cap);
-    RAG_HIP(hipGetLastError());
-    return RAG_OK;
-}
-
-template <bool BF>
-int launch_spec(const MfmaPlan& p, const Args& a) {
-    const size_t smem = pipe_smem_need();
-    const bool sample = a.thr_q == nullptr;
-    auto fn = a.metric == RAG_METRIC_IP ? (sample ? flat_spec_kernel<RAG_METRIC_IP, BF, true> : flat_spec_kernel<RAG_METRIC_IP, BF, false>)
-                                        : (sample ? flat_spec_kernel<RAG_METRIC_L2, BF, true> : flat_spec_kernel<RAG_METRIC_L2, BF, false>);
-    RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    fn<<<(unsigned)(p.S * p.col_tiles), 768, smem, a.st>>>(a.X, a.n, a.ld, a.Qp, a.nq, p.S, p.col_tiles, a.cand_key,
                                                           a.cand_id, a.xnorm, a.qnorm, a.zero16, (long long)p.tile_step,
                                                           a.run_flag, a.thr_q, a.counts, p.cap);
     RAG_HIP(hipGetLastError());
@@ -578,9 +561,6 @@ int dispatch(const MfmaPlan& p, const Args& a) {
             case 9:
                 if (a.ld % 32 != 0) return fail(RAG_ERR_INVALID_ARG, "block shape 10 needs rows of whole 128-byte stages");
                 return launch_pipe<BF>(p, a);
-            case 10:
-                if (a.ld % 32 != 0) return fail(RAG_ERR_INVALID_ARG, "block shape 11 needs rows of whole 128-byte stages");
-                return launch_spec<BF>(p, a);
             default: return fail(RAG_ERR_INVALID_ARG, "no filter-mode kernel for block shape %d", p.shape + 1);
         }
     }
@@ -593,8 +573,7 @@ int dispatch(const MfmaPlan& p, const Args& a) {
         case 5: return RAG_MFMA_4W(2, 2, 4, 32);
         case 6: return RAG_MFMA_4W(1, 4, 8, 32);
         case 7: return RAG_MFMA_NS(1, 8, 8, 1, 32, 1, false);
-        case 9:
-        case 10: return fail(RAG_ERR_INVALID_ARG, "block shapes 10 and 11 are filter-mode shapes");
+        case 9: return fail(RAG_ERR_INVALID_ARG, "block shape 10 is a filter-mode shape");
         default: return RAG_MFMA_NS(2, 4, 4, 2, 16, 1, false);
     }
 #undef RAG_MFMA_4W

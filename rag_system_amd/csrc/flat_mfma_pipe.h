@@ -189,14 +189,6 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
 #endif
         if (px_tiles_left > 0) {
             const char* base = Xb + ((long long)px_row0 * ld + px_ks * BK) * 4;
-#ifdef RAG_PIPE_XBLOCKED
-            // experiment (timing only, wrong data): the row stage as ONE contiguous 32 KiB block, as a
-            // tile-blocked arena [row tile][K stage][256 rows x 128 B] would hold it
-            if (true) {
-                const char* blk = Xb + ((long long)(px_row0 / BM) * nk + px_ks) * (STG * 4LL);
-                glds16(blk + ((it * NWV + wid) * 64 + lane) * 16, dst);
-            } else
-#endif
             if (px_row0 + BM <= nrows) {
                 RAG_GLDS(base + it * row_stride + (unsigned long long)lane_off, dst, Xb, (long long)n * ld * 4, 1);
             } else {  // the last, partial row tile: rows past the end re-read the last row (masked in the epilogue)
