@@ -116,6 +116,16 @@ int rag_flat_reset(rag_flat_t* h);
  * Ties: lower id first.  k > ntotal: tail padded with I=-1 and
  * D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= RAG_MAX_K_TOTAL. */
 int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I);
+/* rag_flat_search in two halves, for callers whose next step does not depend on the result yet:
+ * _begin copies the queries, enqueues the search on the handle's own stream and returns; _end waits
+ * for it and delivers D / I (nq x k, as rag_flat_search).  search_engine.py:266-267 (and :230-231,
+ * :170-173) ask for the dense ranking and then the BM25 ranking of the same query, one after the
+ * other; behind _begin the BM25 / TF-IDF scoring runs beside the dense pass.  One begun search per
+ * handle; other searches and adds on the handle are refused / ordered behind it until _end.
+ * nq * (d + 3k) * 4 bytes must stay under 4 MiB (the results are written straight into a pinned
+ * staging buffer by the search's last kernel). */
+int rag_flat_search_begin(rag_flat_t* h, int64_t nq, const float* q, int k);
+int rag_flat_search_end(rag_flat_t* h, float* D, int64_t* I);
 /* Same, device-resident query and outputs, asynchronous on `stream`;
  * returned ids are id_base + local row (id_base = first global row of this
  * shard when the corpus is row-sharded over ranks). */

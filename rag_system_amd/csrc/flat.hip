@@ -674,6 +674,9 @@ struct rag_flat {
     float* ws_cvt = nullptr; int64_t ws_cvt_cap = 0;   // fp32 staging for bfloat16 conversion
     unsigned short* ws_qb = nullptr; int64_t ws_qb_cap = 0;  // bfloat16 queries (MFMA operand)
     float* ws_qt = nullptr; int64_t ws_qt_cap = 0;           // queries as block shape 10's LDS image
+    hipStream_t async_st = nullptr;                           // rag_flat_search_begin / _end: the handle's own stream
+    bool begun = false;                                       // ... a begun search owns the pinned buffer until it is ended
+    size_t begun_doff = 0, begun_ioff = 0, begun_db = 0, begun_ib = 0;
     unsigned int* ws_ticket = nullptr;                        // arrival counter of the stream kernel's fused merge (zero between launches)
     std::vector<float> staged;  // host rows not yet flushed (d floats each)
     // search workspace (HBM)
@@ -1460,6 +1463,7 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_qb);
         (void)hipFree(h->ws_qt);
         (void)hipFree(h->ws_ticket);
+        if (h->async_st) (void)hipStreamDestroy(h->async_st);
         (void)hipFree(h->ws_cvt);
         (void)hipFree(h->ws_key);
         (void)hipFree(h->ws_id);
@@ -1619,21 +1623,37 @@ int rag_flat_search_dev_noalloc(rag_flat_t* h, int64_t nq, const float* q_dev, i
                                  (hipStream_t)stream, g_scratch_ptr);
 }
 
-int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I) {
-    RAG_REQUIRE_INIT();
-    if (!h || nq < 0 || (nq > 0 && (!q || !D || !I)))
-        return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
-    if (k < 1 || k > RAG_MAX_K_TOTAL) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K_TOTAL);
-    if (nq == 0) return RAG_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
+namespace {
+
+// Host-buffer search, enqueue part: queries to the device, search_device on `st`, results on their way back.
+// staged (small batches, the reference's one query per call): queries and results go through the handle's
+// pinned buffer, so the transfers are asynchronous DMA behind ONE synchronisation; direct: the search's last
+// kernel writes D / I straight into that pinned buffer (no copy back at all).  Caller holds h->mu.
+struct HostSearch {
+    bool staged = false;
+    size_t ioff = 0, doff = 0, db = 0, ib = 0;
+};
+
+int host_search_enqueue(rag_flat* h, int64_t nq, const float* q, int k, float* D, int64_t* I, hipStream_t st,
+                        bool direct, HostSearch* hs) {
     int rc = flush_staged(h);
     if (rc) return rc;
-    hipStream_t st = lib_stream();
     rc = order_after_previous(h, st);
     if (rc) return rc;
     rc = grow(h->ws_hq, h->ws_hq_cap, nq * h->d);
     if (rc) return rc;
-    if (nq * k > h->ws_out_cap) {
+    const size_t qb = (size_t)nq * h->d * sizeof(float);
+    hs->db = (size_t)nq * k * sizeof(float);
+    hs->ib = (size_t)nq * k * sizeof(long long);
+    const size_t qoff = 0;
+    hs->ioff = (qb + 15) & ~(size_t)15;
+    hs->doff = hs->ioff + ((hs->ib + 15) & ~(size_t)15);
+    const size_t need = hs->doff + hs->db;
+    hs->staged = need <= ((size_t)4 << 20);
+    if (direct && !hs->staged)
+        return fail(RAG_ERR_UNSUPPORTED, "rag_flat_search_begin: nq * (d + 3k) * 4 bytes must stay under 4 MiB (nq=%lld, k=%d)",
+                    (long long)nq, k);
+    if (!direct && nq * k > h->ws_out_cap) {
         if (h->ws_D) RAG_HIP(hipFree(h->ws_D));
         if (h->ws_I) RAG_HIP(hipFree(h->ws_I));
         h->ws_D = nullptr; h->ws_I = nullptr; h->ws_out_cap = 0;
@@ -1642,36 +1662,78 @@ int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, 
         RAG_HIP(hipMalloc(&h->ws_I, (size_t)want * sizeof(long long)));
         h->ws_out_cap = want;
     }
-    // Small batches (the reference's one query per call): queries and results go through a pinned
-    // staging buffer, so the three copies are truly asynchronous DMA transfers behind one
-    // synchronisation instead of three staged pageable copies.
-    const size_t qb = (size_t)nq * h->d * sizeof(float), db = (size_t)nq * k * sizeof(float),
-                 ib = (size_t)nq * k * sizeof(long long);
-    const size_t qoff = 0, ioff = (qb + 15) & ~(size_t)15, doff = ioff + ((ib + 15) & ~(size_t)15);
-    const size_t need = doff + db;
-    const bool staged = need <= ((size_t)4 << 20);
-    if (staged && need > h->pin_cap) {
+    if (hs->staged && need > h->pin_cap) {
         if (h->pin) RAG_HIP(hipHostFree(h->pin));
         h->pin = nullptr; h->pin_cap = 0;
         const size_t want = std::max<size_t>(need, (size_t)64 << 10);
         RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), want, hipHostMallocDefault));
         h->pin_cap = want;
     }
-    if (staged) {
+    if (hs->staged) {
         std::memcpy(h->pin + qoff, q, qb);
         RAG_HIP(hipMemcpyAsync(h->ws_hq, h->pin + qoff, qb, hipMemcpyHostToDevice, st));
     } else {
         RAG_HIP(hipMemcpyAsync(h->ws_hq, q, qb, hipMemcpyHostToDevice, st));
     }
+    if (direct)
+        return search_device(h, nq, h->ws_hq, k, reinterpret_cast<float*>(h->pin + hs->doff),
+                             reinterpret_cast<long long*>(h->pin + hs->ioff), 0, st);
     rc = search_device(h, nq, h->ws_hq, k, h->ws_D, h->ws_I, 0, st);
     if (rc) return rc;
-    RAG_HIP(hipMemcpyAsync(staged ? (void*)(h->pin + doff) : (void*)D, h->ws_D, db, hipMemcpyDeviceToHost, st));
-    RAG_HIP(hipMemcpyAsync(staged ? (void*)(h->pin + ioff) : (void*)I, h->ws_I, ib, hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(hs->staged ? (void*)(h->pin + hs->doff) : (void*)D, h->ws_D, hs->db, hipMemcpyDeviceToHost, st));
+    RAG_HIP(hipMemcpyAsync(hs->staged ? (void*)(h->pin + hs->ioff) : (void*)I, h->ws_I, hs->ib, hipMemcpyDeviceToHost, st));
+    return RAG_OK;
+}
+
+}  // namespace
+
+int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I) {
+    RAG_REQUIRE_INIT();
+    if (!h || nq < 0 || (nq > 0 && (!q || !D || !I)))
+        return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
+    if (k < 1 || k > RAG_MAX_K_TOTAL) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K_TOTAL);
+    if (nq == 0) return RAG_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun) return fail(RAG_ERR_INVALID_ARG, "rag_flat_search: a search begun with rag_flat_search_begin has not been ended");
+    hipStream_t st = lib_stream();
+    HostSearch hs;
+    int rc = host_search_enqueue(h, nq, q, k, D, I, st, false, &hs);
+    if (rc) return rc;
     RAG_HIP(hipStreamSynchronize(st));
-    if (staged) {
-        std::memcpy(D, h->pin + doff, db);
-        std::memcpy(I, h->pin + ioff, ib);
+    if (hs.staged) {
+        std::memcpy(D, h->pin + hs.doff, hs.db);
+        std::memcpy(I, h->pin + hs.ioff, hs.ib);
     }
+    return RAG_OK;
+}
+
+int rag_flat_search_begin(rag_flat_t* h, int64_t nq, const float* q, int k) {
+    RAG_REQUIRE_INIT();
+    if (!h || nq < 1 || !q) return fail(RAG_ERR_INVALID_ARG, "bad handle, nq or NULL buffer");
+    if (k < 1 || k > RAG_MAX_K_TOTAL) return fail(RAG_ERR_INVALID_ARG, "k=%d out of range [1,%d]", k, RAG_MAX_K_TOTAL);
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun) return fail(RAG_ERR_INVALID_ARG, "rag_flat_search_begin: the previous begun search has not been ended");
+    if (!h->async_st) RAG_HIP(hipStreamCreateWithFlags(&h->async_st, hipStreamNonBlocking));
+    HostSearch hs;
+    const int rc = host_search_enqueue(h, nq, q, k, nullptr, nullptr, h->async_st, true, &hs);
+    if (rc) return rc;
+    h->begun = true;
+    h->begun_doff = hs.doff;
+    h->begun_ioff = hs.ioff;
+    h->begun_db = hs.db;
+    h->begun_ib = hs.ib;
+    return RAG_OK;
+}
+
+int rag_flat_search_end(rag_flat_t* h, float* D, int64_t* I) {
+    RAG_REQUIRE_INIT();
+    if (!h || !D || !I) return fail(RAG_ERR_INVALID_ARG, "bad handle or NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->begun) return fail(RAG_ERR_INVALID_ARG, "rag_flat_search_end: no search has been begun on this handle");
+    h->begun = false;
+    RAG_HIP(hipStreamSynchronize(h->async_st));
+    std::memcpy(D, h->pin + h->begun_doff, h->begun_db);
+    std::memcpy(I, h->pin + h->begun_ioff, h->begun_ib);
     return RAG_OK;
 }
 

@@ -63,6 +63,19 @@ class _HipFlatBackend:
         _lib.check(self._lib.rag_flat_search(self._h, nq, _lib.ptr(q), int(k), _lib.ptr(D), _lib.ptr(I)), self._lib)
         return D, I
 
+    def search_begin(self, q, k):
+        """First half of search(): enqueues the search on the handle's own stream and returns; the
+        result is delivered by search_end().  One begun search per index."""
+        _lib.check(self._lib.rag_flat_search_begin(self._h, q.shape[0], _lib.ptr(q), int(k)), self._lib)
+        return (q.shape[0], int(k))
+
+    def search_end(self, pending):
+        nq, k = pending
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self._lib.rag_flat_search_end(self._h, _lib.ptr(D), _lib.ptr(I)), self._lib)
+        return D, I
+
     def search_dev(self, nq, q_dev, k, D_dev, I_dev, id_base=0, stream=0):
         """Asynchronous on `stream` (a hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream;
         0 = HIP's null stream = torch's default stream): ordered with the caller's other work there."""
@@ -142,6 +155,25 @@ class IndexFlat:
         if x.shape[0] == 0:
             return np.empty((0, k), dtype=np.float32), np.empty((0, k), dtype=np.int64)
         return self._b.search(x, k)
+
+    def search_begin(self, x, k):
+        """search() in two halves (not in faiss): returns a token for search_end().  The dense pass runs
+        on the index's own stream while the caller does something else -- rag_system_amd.search_engine
+        computes the BM25 ranking of the same query meanwhile (search_engine.py:266-267)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError("search expects a (nq, %d) float32 array, got %s" % (self.d, x.shape))
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        small = x.shape[0] * (self.d * 4 + 12 * k) + 64 <= (4 << 20)   # fits the pinned staging buffer
+        if x.shape[0] == 0 or not small or not hasattr(self._b, "search_begin"):
+            return ("done", self.search(x, k))        # nothing to overlap (or a backend without the split)
+        return ("pending", self._b.search_begin(x, k))
+
+    def search_end(self, token):
+        kind, val = token
+        return val if kind == "done" else self._b.search_end(val)
 
     def reset(self):
         self._b.reset()

@@ -100,23 +100,48 @@ class SearchEngine:
                 g["chunks"].append(r["chunk"])
         return groups
 
-    def _dense_chunks(self, query, k):
+    def _dense_chunks_begin(self, query, k):
+        """The dense pass in two halves: the reference computes the dense ranking and then the BM25
+        ranking of the same query (search_engine.py:266-267, :230-231, :170-173); they do not depend
+        on each other, so the flat search is enqueued here (rag_flat_search_begin) and the sparse
+        scoring runs beside it.  Stores without the split (test backends) search at once."""
         q_vec = self.embedding_manager.embed_query(query)
-        hits = self.vector_storage.search(q_vec, top_k=k)
+        vs = self.vector_storage
+        if hasattr(vs, "search_begin"):
+            return vs.search_begin(q_vec, top_k=k)
+        return ("done", vs.search(q_vec, top_k=k))
+
+    def _dense_chunks_end(self, token):
+        vs = self.vector_storage
+        hits = vs.search_end(token) if hasattr(vs, "search_end") else token[1]
         for r in hits:
             r["score"] = float(r["score"])
         return hits
 
+    def _dense_chunks(self, query, k):
+        return self._dense_chunks_end(self._dense_chunks_begin(query, k))
+
     # ------------------------------------------------------------------ single-signal strategies
 
     def search_faiss(self, query: str, top_k=10, retrieval_mode="chunk") -> List[Dict[str, Any]]:
+        return self._search_faiss_end(self._search_faiss_begin(query, top_k, retrieval_mode))
+
+    def _search_faiss_begin(self, query, top_k, retrieval_mode):
         if "faiss" not in self.vector_storage.indices_present:
+            return None
+        k = top_k * 3 if retrieval_mode == "document" else top_k
+        return (self._dense_chunks_begin(query, k), query, top_k, retrieval_mode)
+
+    def _search_faiss_end(self, pending):
+        if pending is None:
             return []
+        token, query, top_k, retrieval_mode = pending
+        hits = self._dense_chunks_end(token)
         if retrieval_mode == "document":
-            groups = self._group_dense_by_doc(self._dense_chunks(query, top_k * 3))
+            groups = self._group_dense_by_doc(hits)
             results = [{"doc_id": d, "score": g["score"], "text": " ".join(g["chunks"])} for d, g in groups.items()]
         else:
-            results = self._dense_chunks(query, top_k)
+            results = hits
         if self.cross_encoder:
             results = self.rerank_with_cross_encoder(query, results, normalize_ce=True)
         results.sort(key=lambda x: x["score"], reverse=True)
@@ -165,12 +190,13 @@ class SearchEngine:
     # ------------------------------------------------------------------ hybrid (dense + bm25, raw scores)
 
     def search_hybrid(self, query: str, top_k=10, retrieval_mode="chunk") -> List[Dict[str, Any]]:
-        dense = []
+        pending = None
         if "faiss" in self.vector_storage.indices_present:
-            dense = self._dense_chunks(query, top_k * 3 if retrieval_mode == "document" else top_k)
+            pending = self._dense_chunks_begin(query, top_k * 3 if retrieval_mode == "document" else top_k)
         sparse = []
         if "bm25" in self.vector_storage.indices_present:
-            sparse = self.search_bm25(query, top_k=top_k, retrieval_mode=retrieval_mode)
+            sparse = self.search_bm25(query, top_k=top_k, retrieval_mode=retrieval_mode)   # beside the dense pass
+        dense = self._dense_chunks_end(pending) if pending is not None else []
         fused = {}
         if retrieval_mode == "document":
             groups = self._group_dense_by_doc(dense)
@@ -227,8 +253,10 @@ class SearchEngine:
     # ------------------------------------------------------------------ multi (dense + bm25 + tfidf, max-normalised)
 
     def search_multi_representation(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
-        dense = {d["doc_id"]: d["score"] for d in self.search_faiss(query, top_k=top_k * 3, retrieval_mode="document")}
-        bm25 = {d["doc_id"]: d["score"] for d in self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")}
+        pending = self._search_faiss_begin(query, top_k * 3, "document")
+        bm25_hits = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")   # beside the dense pass
+        dense = {d["doc_id"]: d["score"] for d in self._search_faiss_end(pending)}
+        bm25 = {d["doc_id"]: d["score"] for d in bm25_hits}
         cand_ids = list(dict.fromkeys(list(dense) + list(bm25)))
         tf = self._tfidf_for_candidates(query, cand_ids, top_k + len(cand_ids))
         tfidf = {}
@@ -263,8 +291,9 @@ class SearchEngine:
     # ------------------------------------------------------------------ rrf
 
     def search_rrf(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
-        dense_ranking = self.search_faiss(query, top_k=top_k * 3, retrieval_mode="document")
-        bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+        pending = self._search_faiss_begin(query, top_k * 3, "document")
+        bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")   # beside the dense pass
+        dense_ranking = self._search_faiss_end(pending)
         fused = self.reciprocal_rank_fusion(dense_ranking, bm25_ranking, k=60)
         tf = self._tfidf_for_candidates(query, list(fused), top_k + len(fused))
         if tf is not None:

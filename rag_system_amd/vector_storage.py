@@ -107,6 +107,26 @@ class VectorStorage:
                          "source": cdata["source"]})
         return hits
 
+    def search_begin(self, query_vector, top_k=5):
+        """search() in two halves (not in the reference): the dense pass is enqueued and runs while the
+        caller computes something else; search_end(token) returns what search() would have."""
+        if self.index.ntotal == 0 or not hasattr(self.index, "search_begin"):
+            return ("done", self.search(query_vector, top_k))
+        q = np.array(query_vector, dtype="float32").reshape(1, -1)
+        return ("pending", self.index.search_begin(q, top_k))
+
+    def search_end(self, token):
+        kind, val = token
+        if kind == "done":
+            return val
+        distances, indices = self.index.search_end(val)
+        hits = []
+        for dist, idx in zip(distances[0], indices[0]):
+            cdata = self.chunks_data[idx]   # idx == -1 (k > ntotal) is the last chunk, as in the reference
+            hits.append({"doc_id": cdata["doc_id"], "score": float(dist), "chunk": cdata["chunk"],
+                         "source": cdata["source"]})
+        return hits
+
     def search_batch(self, query_vectors, top_k=5):
         """Many queries in one index.search call (nq x d) -- the batched front end the reference
         lacks; per query the same list search() returns."""

@@ -202,3 +202,48 @@ def test_two_streams_on_one_handle_do_not_overlap(engine):
         _, Ir, D64 = od.flat_search(X, Q, k, 0)
         od.check_topk(Dd.cpu().numpy(), Id.cpu().numpy(), D64, Ir, 1e-5, 2e-6,
                       lambda qi, ids: X64[ids] @ Q[qi].astype(np.float64))
+
+
+def test_search_begin_end_equals_search_and_overlaps_sparse_scoring(engine):
+    """rag_flat_search_begin / _end: the same (D, I) as rag_flat_search, bit for bit, with a BM25 scoring
+    on the library stream between the two halves; misuse is refused with a clear error."""
+    from rag_system_amd import faiss_compat as faiss
+    from rag_system_amd.bm25 import BM25Okapi
+    rng = np.random.default_rng(31)
+    n, d = 60_000, 96
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    idx = faiss.IndexFlatIP(d)
+    idx.add(X)
+    indptr = np.arange(0, 20 * 5000 + 1, 20, dtype=np.int64)
+    bm = BM25Okapi.from_term_ids(indptr, rng.integers(0, 300, 20 * 5000))
+    ref_scores = bm.get_scores([1, 2, 3])
+    for nq, k in [(1, 10), (1, 90), (3, 7), (40, 100), (1, 300)]:
+        Q = rng.standard_normal((nq, d)).astype(np.float32)
+        D0, I0 = idx.search(Q, k)
+        tok = idx.search_begin(Q, k)
+        assert tok[0] == "pending"
+        s = bm.get_scores([1, 2, 3])                       # sparse scoring beside the dense pass
+        D1, I1 = idx.search_end(tok)
+        assert np.array_equal(I0, I1) and np.array_equal(D0, D1), (nq, k)
+        assert np.array_equal(s, ref_scores)
+    # a batch beyond the pinned staging buffer is searched at once
+    Qb = rng.standard_normal((12_000, d)).astype(np.float32)
+    tok = idx.search_begin(Qb, 10)
+    assert tok[0] == "done"
+    D1, I1 = idx.search_end(tok)
+    D0, I0 = idx.search(Qb, 10)
+    assert np.array_equal(I0, I1)
+    # misuse
+    Q = rng.standard_normal((1, d)).astype(np.float32)
+    tok = idx.search_begin(Q, 5)
+    with pytest.raises(ValueError):
+        idx.search_begin(Q, 5)
+    with pytest.raises(ValueError):
+        idx.search(Q, 5)
+    idx.add(X[:10])                                        # an add between the halves is ordered behind the search
+    D1, I1 = idx.search_end(tok)
+    assert I1.max() < n
+    with pytest.raises(ValueError):
+        idx._b.search_end((1, 5))
+    D2, I2 = idx.search(Q, 5)
+    assert np.array_equal(I1, I2) or I2.max() >= n         # the ten new rows may now appear
