@@ -22,9 +22,9 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
-for src, dst in (("default_stats", "bench_default"), ("c3_stats", "bench_c3_bf16_nq1024_k100"), ("hyb_stats", "bench_hybrid_1m")):
+for src, dst in (("default_stats", "bench_default"), ("nq1_stats", "bench_nq1"), ("c3_stats", "bench_c3_bf16_nq1024_k100"), ("hyb_stats", "bench_hybrid_1m")):
     shutil.copy(newest(P + src + "/*/*_kernel_stats.csv"), "profiles/%s_%s_kernel_stats.csv" % (tag, dst))
-for src, dst in (("default_under_rocprof", "bench_default_under_rocprof"), ("c3_under_rocprof", "bench_c3_under_rocprof"),
+for src, dst in (("default_under_rocprof", "bench_default_under_rocprof"), ("nq1_under_rocprof", "bench_nq1_under_rocprof"), ("c3_under_rocprof", "bench_c3_under_rocprof"),
                  ("hyb_under_rocprof", "bench_hybrid_1m_under_rocprof")):
     shutil.copy(P + src + ".json", "profiles/%s_%s.json" % (tag, dst))
 
@@ -55,3 +55,10 @@ d["derived"] = {"cycles_per_xcd": cyc, "mfma_busy_frac": d["SQ_VALU_MFMA_BUSY_CY
                         "clock = cycles_per_xcd / the kernel's duration in the kernel stats of the same workload"}
 json.dump({"bf16_768_nq1024_k100_pipelined_kernel_filter_pass": d}, open("profiles/%s_mfma_pmc.json" % tag, "w"), indent=1)
 print(json.dumps(d["derived"], indent=1))
+
+# agreement of the two clocks on the batch-1 kernel (same run)
+import csv
+r = json.load(open("profiles/%s_bench_nq1_under_rocprof.json" % tag))
+rows = [x for x in csv.DictReader(open("profiles/%s_bench_nq1_kernel_stats.csv" % tag)) if "flat_stream_kernel" in x["Name"]]
+print("batch-1 kernel: rocprofv3 average %.4f ms over %s launches; HIP events in the same run %.4f ms over %d launches"
+      % (float(rows[0]["AverageNs"]) / 1e6, rows[0]["Calls"], r["roofline"]["avg_launch_ms"], r["roofline"]["launches"]))

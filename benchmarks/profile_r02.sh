@@ -9,6 +9,9 @@ NQ1="bench.py --no-cpu-baseline --no-batch-leg --no-legs --steps 50 --warmup 5"
 C3="bench.py --no-cpu-baseline --no-legs --storage bf16 --dim 768 --k 100 --nq 1024 --steps 3 --warmup 1"
 # 1. exactly the default command
 run default_stats --kernel-trace --stats -d $O/default_stats --output-format csv -- python3 bench.py
+# 1b. the headline alone (every launch of the batch-1 kernel has the same size: its average is comparable
+#     with roofline.avg_launch_ms of the same run)
+run nq1_stats --kernel-trace --stats -d $O/nq1_stats --output-format csv -- python3 $NQ1
 # 2. HBM traffic of the batch-1 kernel
 run nq1_fetch --pmc FETCH_SIZE -d $O/nq1_fetch --output-format csv -- python3 $NQ1
 run nq1_write --pmc WRITE_SIZE -d $O/nq1_write --output-format csv -- python3 $NQ1
@@ -23,6 +26,7 @@ for d in nq1_fetch nq1_write; do python3 benchmarks/pmc_summary.py $O/$d flat_st
 for d in c3_sq c3_grbm c3_fetch; do python3 benchmarks/pmc_summary.py $O/$d flat_pipe_kernel --skip 1 > $O/$d.json; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 grep -h "^{" $O/default_stats.log | tail -1 > $O/default_under_rocprof.json
+grep -h "^{" $O/nq1_stats.log | tail -1 > $O/nq1_under_rocprof.json
 grep -h "^{" $O/c3_stats.log | tail -1 > $O/c3_under_rocprof.json
 grep -h "^{" $O/hyb_stats.log | tail -1 > $O/hyb_under_rocprof.json
 ls -R $O | head -60
