@@ -21,6 +21,7 @@ using namespace rag;
 constexpr int CAND_THREADS = 1024;
 constexpr int RRF_MAX_ENTRIES = 16384;
 constexpr int MMR_MAX_C = 2048;
+constexpr int MMR_SMALL_C = 64;
 
 // ids: all rankings concatenated (entry e belongs to ranking r with rank e - start[r]).
 // first[e] = smallest e' <= e with the same id.  An id's score is accumulated by the thread
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __re
                                                            long long* __restrict__ out_ids,
                                                            double* __restrict__ out_scores, int* __restrict__ n_out,
                                                            int* __restrict__ first_g) {
-    __shared__ int s_count[CAND_THREADS];
+    __shared__ int s_count[CAND_THREADS / 64];
     __shared__ long long s_ids[LDS ? RRF_LDS_T : 1];
     __shared__ int s_rank[LDS ? RRF_LDS_T : 1];
     __shared__ int s_first[LDS ? RRF_LDS_T : 1];
@@ -70,19 +71,29 @@ __global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __re
     const int lo = tid * per, hi = min(T, lo + per);
     int cnt = 0;
     for (int e = lo; e < hi; ++e) cnt += first[e] == e;
-    s_count[tid] = cnt;
+    // exclusive prefix of the per-thread counts: a scan inside each wave, then one over the 16 wave totals
+    // (thread 0 walking all 1024 counts alone was most of this kernel's 20 us)
+    const int lane = tid & 63, wid = tid >> 6;
+    int incl = cnt;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const int y = __shfl_up(incl, dd);
+        if (lane >= dd) incl += y;
+    }
+    if (lane == 63) s_count[wid] = incl;
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < CAND_THREADS; ++i) {
-            const int c = s_count[i];
-            s_count[i] = run;
-            run += c;
+    if (wid == 0) {
+        constexpr int NW = CAND_THREADS / 64;
+        const int w = lane < NW ? s_count[lane] : 0;
+        int ws = w;
+        for (int dd = 1; dd < NW; dd <<= 1) {
+            const int y = __shfl_up(ws, dd);
+            if (lane >= dd) ws += y;
         }
-        *n_out = run;
+        if (lane < NW) s_count[lane] = ws - w;
+        if (lane == NW - 1) *n_out = ws;
     }
     __syncthreads();
-    int o = s_count[tid];
+    int o = s_count[wid] + incl - cnt;
     for (int e = lo; e < hi; ++e) {
         if (first[e] != e) continue;
         const long long id = ids[e];
@@ -121,6 +132,8 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
     __shared__ float s_qinv;
     __shared__ int s_pick;
     __shared__ long long s_bytes[MMR_MAX_C];  // read once: the inputs may sit in pinned host memory
+    __shared__ float s_G[MMR_SMALL_C * MMR_SMALL_C];  // C <= 64: the Gram matrix never leaves the CU
+    const bool small = C <= MMR_SMALL_C;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = CAND_THREADS / 64;
     for (int i = tid; i < C; i += CAND_THREADS) s_bytes[i] = byte_len[i];
@@ -175,8 +188,13 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
         for (int dist = 32; dist >= 1; dist >>= 1) s += __shfl_xor(s, dist);
         if (lane == 0) {
             const float v = s / (s_inv[i] * s_inv[j]);
-            G[(size_t)i * C + j] = v;
-            G[(size_t)j * C + i] = v;
+            if (small) {
+                s_G[i * MMR_SMALL_C + j] = v;
+                s_G[j * MMR_SMALL_C + i] = v;
+            } else {
+                G[(size_t)i * C + j] = v;
+                G[(size_t)j * C + i] = v;
+            }
         }
     }
     for (int i = tid; i < C; i += CAND_THREADS) {
@@ -184,6 +202,55 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
         s_maxsim[i] = -FLT_MAX;
     }
     __syncthreads();
+
+    if (small) {
+        // Up to 64 candidates (every call the search engine makes: top_k .. a few times top_k): ONE wave runs
+        // the greedy loop, candidate i in lane i -- same scores, same comparisons, same order as the block-wide
+        // loop below (first index wins ties, like np.argmax), without two barriers and an LDS hand-off per pick.
+        if (wid != 0) return;
+        const bool live0 = lane < C;
+        const double sq = live0 ? (double)simq[lane] : 0.0;
+        const long long bytes = live0 ? s_bytes[lane] : 0;
+        float maxsim = -FLT_MAX;
+        bool dead = !live0;
+        int n_sel = 0, remaining = C, last = -1;
+        long long total_bytes = 0;
+        bool first_pick = true;
+        while (remaining > 0 && n_sel < top_k) {
+            if (last >= 0 && !dead) maxsim = fmaxf(maxsim, s_G[lane * MMR_SMALL_C + last]);
+            double best = dead ? -DBL_MAX : (first_pick ? sq : lambda * sq - (1.0 - lambda) * (double)maxsim);
+            int besti = dead ? INT_MAX : lane;
+            if (!(best > -DBL_MAX)) {  // NaN (or dead): never picked, and must not poison the butterfly below
+                best = -DBL_MAX;
+                besti = INT_MAX;
+            }
+            for (int dist = 32; dist >= 1; dist >>= 1) {
+                const double ob = __shfl_xor(best, dist);
+                const int oi = __shfl_xor(besti, dist);
+                if (ob > best || (ob == best && oi < besti)) {
+                    best = ob;
+                    besti = oi;
+                }
+            }
+            const int pick = besti;
+            if (pick >= C) break;  // only NaN scores left
+            last = -1;
+            const long long pb = __shfl(bytes, pick);
+            bool take = true;
+            if (!first_pick && max_bytes >= 0 && total_bytes + pb > max_bytes) take = false;
+            if (take) {
+                total_bytes += pb;
+                if (lane == 0) out_order[n_sel] = pick;
+                ++n_sel;
+                last = pick;
+            }
+            if (lane == pick) dead = true;
+            --remaining;
+            first_pick = false;
+        }
+        if (lane == 0) *out_n = n_sel;
+        return;
+    }
 
     int n_sel = 0;
     long long total_bytes = 0;
