@@ -116,6 +116,21 @@ int rag_flat_reset(rag_flat_t* h);
  * Ties: lower id first.  k > ntotal: tail padded with I=-1 and
  * D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= RAG_MAX_K_TOTAL. */
 int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, int64_t* I);
+/* Opt-in bfloat16 prefilter of an fp32 index.  No counterpart in the reference (vector_storage.py:196 is a
+ * plain faiss IndexFlat search); the results stay those of the fp32 rows.  enable != 0: the index keeps a
+ * bfloat16 copy of its rows (+50 % HBM, filled by the next search and kept up to date by later ones).
+ * Searches with k <= 32 on shards of "prefilter_min_rows" rows or more then stream the copy for 64 (up to
+ * 8 queries, k <= 16) or 128 candidates per query, score the candidates again from the fp32 rows (float64
+ * accumulation, one rounding to fp32) and check per query that no other row can reach the top k:
+ * |bf16 score - exact score| <= (2^-7 + 2^-16 + (d+16) 2^-23) ||x|| ||q||.  A query whose check does not
+ * close is searched again on the fp32 rows (device side, same call).  Scores may differ from the plain
+ * fp32 search in the last bits (another summation order); ids only between rows whose fp32 scores tie.
+ * enable == 0: the copy is freed.  bfloat16-stored indexes: RAG_ERR_UNSUPPORTED. */
+int rag_flat_prefilter(rag_flat_t* h, int enable);
+/* How many queries of the last search on this handle the prefilter could not prove and searched again on
+ * the fp32 rows (0 when that search did not use the prefilter).  Waits for the device.  Diagnostic: a
+ * corpus whose neighbours lie closer together than a bfloat16 rounding pays for both passes. */
+int rag_flat_prefilter_redone(rag_flat_t* h, int64_t* n_queries);
 /* rag_flat_search in two halves, for callers whose next step does not depend on the result yet:
  * _begin copies the queries, enqueues the search on the handle's own stream and returns; _end waits
  * for it and delivers D / I (nq x k, as rag_flat_search).  search_engine.py:266-267 (and :230-231,

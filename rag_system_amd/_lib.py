@@ -65,6 +65,8 @@ SIGNATURES = {
     "rag_flat_last_kernel": (C.c_char_p, [_p]),
     "rag_flat_reset": (C.c_int, [_p]),
     "rag_flat_search": (C.c_int, [_p, _i64, _p, C.c_int, _p, _p]),
+    "rag_flat_prefilter": (C.c_int, [_p, C.c_int]),
+    "rag_flat_prefilter_redone": (C.c_int, [_p, _p]),
     "rag_flat_search_begin": (C.c_int, [_p, _i64, _p, C.c_int]),
     "rag_flat_search_end": (C.c_int, [_p, _p, _p]),
     "rag_flat_search_dev": (C.c_int, [_p, _i64, _p, C.c_int, _p, _p, _i64, _p]),

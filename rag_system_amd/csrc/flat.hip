@@ -620,6 +620,171 @@ __global__ void rows_from_bf16_kernel(const unsigned short* __restrict__ src, in
     }
 }
 
+// ---------------------------------------------------------------- bfloat16 prefilter (rag_flat_prefilter)
+//
+// An fp32 index may keep a bfloat16 copy of its rows (the "shadow", a second arena of half the size).  A
+// search then streams the copy -- half the HBM bytes, and for batches the bf16 matrix cores instead of the
+// fp32 ones -- for kp > k candidates per query, scores those candidates again from the fp32 rows, and
+// PROVES that nothing outside them can belong to the top k:
+//   |<bf16(x), bf16(q)>_computed - <x, q>| <= eps * ||x|| * ||q||,  eps = 2u + u^2 + (d + 16) * 2^-23,  u = 2^-8
+//   (round-to-nearest of both operands, exact products, d fp32 additions; Cauchy-Schwarz on sum |x_i q_i|),
+// so every row outside the candidates scores at most (worst candidate's approximate score) + eps *
+// max||x|| * ||q||.  If the k-th best EXACT score among the candidates is above that bound, the candidates'
+// exact top k is the index' exact top k; otherwise the query is flagged and redone on the fp32 rows by
+// the list-mode tile kernel (the redo path of the filter flow).  The result never depends on bfloat16
+// arithmetic, only the amount of work does.
+
+// fp32 arena rows -> shadow rows (round to nearest even), ||x||^2 per row (L2) and the largest of them.
+__global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restrict__ X, int ld, int d, long long n,
+                                                          unsigned short* __restrict__ S, int sld,
+                                                          float* __restrict__ xn_out, unsigned int* __restrict__ max_bits) {
+    const int lane = threadIdx.x & 63;
+    const long long W = (long long)gridDim.x * 4;
+    float mx = 0.f;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += W) {
+        const float* row = X + r * ld;
+        unsigned short* out = S + r * sld;
+        double ss = 0.0;
+        for (int c = lane; c < sld; c += 64) {
+            const float v = c < d ? row[c] : 0.0f;
+            ss += (double)v * (double)v;
+            out[c] = bf16_rne(v);
+        }
+        for (int dist = 32; dist >= 1; dist >>= 1) ss += __shfl_xor(ss, dist);
+        float nn = (float)ss;
+        if (!(nn >= 0.f)) nn = __builtin_inff();  // NaN in the row: no bound holds, every search is redone exactly
+        if (xn_out != nullptr && lane == 0) xn_out[r] = (float)ss;
+        mx = fmaxf(mx, nn);
+    }
+    if (lane == 0 && mx > 0.f) atomicMax(max_bits, __float_as_uint(mx));
+}
+
+constexpr int PF_MAX_KP = 128;
+
+// One workgroup per query.  pD / pI: the shadow's kp best rows (approximate scores, local ids, -1 = none).
+// Exact scores: float64 accumulation over the fp32 row, rounded once to fp32 (L2: sum of (x - q)^2).
+// Writes the exact top k (ties: lower id first) to D / I and flags the query (failq = 1, ++nfail) when
+// the bound above does not close.
+template <int METRIC>
+__global__ __launch_bounds__(256) void prefilter_rescore_kernel(
+    const float* __restrict__ X, long long n, int ld, int d, const float* __restrict__ Q,
+    const float* __restrict__ pD, const long long* __restrict__ pI, int kp, int k,
+    const unsigned int* __restrict__ max_bits, double eps_rel, double slack, float* __restrict__ D,
+    long long* __restrict__ I, long long id_base, int* __restrict__ nfail, int* __restrict__ failq) {
+    extern __shared__ __align__(16) float s_q[];  // ld floats, pad columns zero
+    __shared__ double s_a[PF_MAX_KP];              // approximate score, larger = better (L2: minus the distance)
+    __shared__ float s_e[PF_MAX_KP];               // exact score, same sense
+    __shared__ int s_id[PF_MAX_KP];
+    __shared__ unsigned char s_need[PF_MAX_KP];
+    __shared__ double s_red[2][4];
+    __shared__ double s_L, s_B;
+    __shared__ float s_Ek;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* qrow = Q + (long long)q * d;
+    double qq = 0.0, qqb = 0.0;
+    for (int c = tid; c < ld; c += 256) {
+        const float v = c < d ? qrow[c] : 0.0f;
+        s_q[c] = v;
+        const float vb = __uint_as_float((unsigned int)bf16_rne(v) << 16);
+        qq += (double)v * (double)v;
+        qqb += (double)vb * (double)vb;
+    }
+    for (int dist = 32; dist >= 1; dist >>= 1) {
+        qq += __shfl_xor(qq, dist);
+        qqb += __shfl_xor(qqb, dist);
+    }
+    if (lane == 0) {
+        s_red[0][wid] = qq;
+        s_red[1][wid] = qqb;
+    }
+    if (tid == 0) {
+        s_L = __builtin_nan("");
+        s_B = __builtin_inf();
+        s_Ek = __builtin_nanf("");
+    }
+    __syncthreads();
+    qq = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    qqb = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    const double mx2 = (double)__uint_as_float(*max_bits);
+    double eps = eps_rel * sqrt(mx2 * qq);
+    if (METRIC == RAG_METRIC_L2) eps = 2.0 * eps + slack * (mx2 + qq);  // + the fp32 roundings of both norms and of the key
+    eps = eps * (1.0 + 1e-6) + 1e-30 * (1.0 + sqrt(qq));
+
+    bool valid = false;
+    double a = -__builtin_inf();
+    if (tid < kp) {
+        const long long id = pI[(long long)q * kp + tid];
+        valid = id >= 0 && id < n;
+        const double v = (double)pD[(long long)q * kp + tid];
+        // the shadow's distance holds ||bf16(q)||^2 where the exact one holds ||q||^2: the same shift for every row
+        if (valid) a = METRIC == RAG_METRIC_IP ? v : -(v - (qqb - qq));
+        s_a[tid] = a;
+        s_id[tid] = valid ? (int)id : -1;
+    }
+    const int nv = __syncthreads_count(valid);
+    const int kk = k < nv ? k : nv;
+    if (valid) {
+        int ra = 0;
+        for (int j = 0; j < kp; ++j) {
+            const double b = s_a[j];
+            ra += (b > a || (b == a && j < tid)) && s_id[j] >= 0;
+        }
+        if (ra == kk - 1) s_L = a - eps;
+        // rows outside the candidates exist only if the shadow filled all kp places
+        if (ra == nv - 1) s_B = (nv == kp && n > (long long)kp) ? a + eps : -__builtin_inf();
+    }
+    __syncthreads();
+    const bool need = valid && (a + eps >= s_L);
+    if (tid < kp) s_need[tid] = need;
+    const int m = __syncthreads_count(need);
+    for (int i = wid; i < kp; i += 4) {
+        if (!s_need[i]) continue;
+        const f32x4* row = reinterpret_cast<const f32x4*>(X + (long long)s_id[i] * ld);
+        const f32x4* qv = reinterpret_cast<const f32x4*>(s_q);
+        double acc = 0.0;
+        for (int c = lane; c < ld / 4; c += 64) {
+            const f32x4 x = row[c], y = qv[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (METRIC == RAG_METRIC_IP) acc += (double)x[e] * (double)y[e];
+                else {
+                    const double df = (double)x[e] - (double)y[e];
+                    acc += df * df;
+                }
+            }
+        }
+        for (int dist = 32; dist >= 1; dist >>= 1) acc += __shfl_xor(acc, dist);
+        if (lane == 0) s_e[i] = METRIC == RAG_METRIC_IP ? (float)acc : -(float)acc;
+    }
+    __syncthreads();
+    if (need) {
+        const float e = s_e[tid];
+        const int id = s_id[tid];
+        int r = 0;
+        for (int j = 0; j < kp; ++j) {
+            if (!s_need[j]) continue;
+            const float b = s_e[j];
+            r += b > e || (b == e && s_id[j] < id);
+        }
+        if (r < k) {
+            D[(long long)q * k + r] = METRIC == RAG_METRIC_IP ? e : -e;
+            I[(long long)q * k + r] = (long long)id + id_base;
+        }
+        if (r == kk - 1) s_Ek = e;
+    }
+    for (int pos = (m < k ? m : k) + tid; pos < k; pos += 256) {
+        D[(long long)q * k + pos] = METRIC == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX;
+        I[(long long)q * k + pos] = -1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // NaN anywhere (scores, norms, query) makes one of these comparisons false: the query is redone
+        const bool ok = m >= kk && kk >= 1 && (double)s_Ek > s_B;
+        failq[q] = ok ? 0 : 1;
+        if (!ok) atomicAdd(nfail, 1);
+    }
+}
+
 // ---------------------------------------------------------------- synthetic rows
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -705,7 +870,14 @@ struct rag_flat {
     hipStream_t last_stream = nullptr;
     bool last_stream_valid = false;
     hipEvent_t order_ev = nullptr;
-    char last_kernel[96] = "";   // which kernels served the last search (rag_flat_last_kernel)
+    // rag_flat_prefilter: bfloat16 copy of the rows ("shadow": its own handle, arena and workspaces), the
+    // largest ||x||^2 among the copied rows (device word, float bits), the candidates of a search
+    rag_flat* shadow = nullptr;
+    unsigned int* sh_max = nullptr;
+    int* last_nfail = nullptr;     // device word of the last prefiltered search: queries it had to redo (rag_flat_prefilter_redone)
+    float* ws_pD = nullptr; int64_t ws_pD_cap = 0;
+    long long* ws_pI = nullptr; int64_t ws_pI_cap = 0;
+    char last_kernel[128] = "";   // which kernels served the last search (rag_flat_last_kernel)
     std::mutex mu;
 };
 
@@ -900,22 +1072,16 @@ int ks_for(int k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
 
 // L2 through the matrix-core kernels is ||x||^2 + ||q||^2 - 2<x,q>: row norms are computed once per
 // added row (kept next to the arena), query norms per call.
+int ensure_norm_array(rag_flat* h, hipStream_t st);
+
 int prepare_l2_norms(rag_flat* h, const float* qf, int64_t nq, hipStream_t st) {
     if (h->metric != RAG_METRIC_L2) return RAG_OK;
     const int64_t n = h->ndev;
     const int ld = h->ld;
     const bool bf = h->dtype == RAG_DTYPE_BF16;
     int rc = RAG_OK;
-    if (h->xnorm_cap < h->cap) {  // follow the arena
-        float* nn = nullptr;
-        RAG_HIP(hipMalloc(&nn, (size_t)h->cap * sizeof(float)));
-        if (h->norm_valid > 0)
-            RAG_HIP(hipMemcpyAsync(nn, h->xnorm, (size_t)h->norm_valid * sizeof(float), hipMemcpyDeviceToDevice, st));
-        RAG_HIP(hipStreamSynchronize(st));
-        if (h->xnorm) RAG_HIP(hipFree(h->xnorm));
-        h->xnorm = nn;
-        h->xnorm_cap = h->cap;
-    }
+    rc = ensure_norm_array(h, st);  // follow the arena
+    if (rc) return rc;
     if (h->norm_valid < n) {
         rc = mfma_row_norms(h->x, ld, bf, h->norm_valid, n - h->norm_valid, h->xnorm, st);
         if (rc) return rc;
@@ -939,6 +1105,56 @@ int order_after_previous(rag_flat* h, hipStream_t st) {
     }
     h->last_stream = st;
     h->last_stream_valid = true;
+    return RAG_OK;
+}
+
+int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_dev, long long* I_dev,
+                  int64_t id_base, hipStream_t st);
+
+// The row-norm array follows the arena's capacity (entries below norm_valid are kept).
+int ensure_norm_array(rag_flat* h, hipStream_t st) {
+    if (h->xnorm_cap >= h->cap) return RAG_OK;
+    float* nn = nullptr;
+    RAG_HIP(hipMalloc(&nn, (size_t)h->cap * sizeof(float)));
+    if (h->norm_valid > 0)
+        RAG_HIP(hipMemcpyAsync(nn, h->xnorm, (size_t)h->norm_valid * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RAG_HIP(hipStreamSynchronize(st));
+    if (h->xnorm) RAG_HIP(hipFree(h->xnorm));
+    h->xnorm = nn;
+    h->xnorm_cap = h->cap;
+    return RAG_OK;
+}
+
+// Bring the bfloat16 shadow of an fp32 index up to its ndev rows (rows are only ever appended; reset empties
+// both).  L2: the shadow's row norms are those of the fp32 rows, so that only the cross term carries the
+// rounding of the copy.  Synchronises `st` when rows were copied (once per add, not per search).
+int sync_shadow(rag_flat* h, hipStream_t st) {
+    rag_flat* sh = h->shadow;
+    if (sh->ndev == h->ndev) return RAG_OK;
+    if (!h->sh_max) RAG_HIP(hipMalloc(&h->sh_max, 256));
+    if (sh->ndev > h->ndev || sh->ndev == 0) {  // after a reset: start again
+        sh->ndev = sh->ntotal = 0;
+        sh->norm_valid = 0;
+        RAG_HIP(hipMemsetAsync(h->sh_max, 0, 256, st));
+    }
+    int rc = ensure_capacity(sh, h->ndev);
+    if (rc) return rc;
+    float* xn = nullptr;
+    if (h->metric == RAG_METRIC_L2) {
+        rc = ensure_norm_array(sh, st);
+        if (rc) return rc;
+        xn = sh->xnorm + sh->ndev;
+    }
+    const int64_t first = sh->ndev, m = h->ndev - first;
+    const int64_t nb = std::min<int64_t>((m + 3) / 4, (int64_t)num_cus() * 16);
+    shadow_rows_kernel<<<(unsigned)nb, 256, 0, st>>>(reinterpret_cast<const float*>(h->x) + (size_t)first * h->ld, h->ld,
+                                                    h->d, (long long)m,
+                                                    reinterpret_cast<unsigned short*>(sh->x) + (size_t)first * sh->ld,
+                                                    sh->ld, xn, h->sh_max);
+    RAG_HIP(hipGetLastError());
+    RAG_HIP(hipStreamSynchronize(st));
+    sh->ndev = sh->ntotal = h->ndev;
+    if (h->metric == RAG_METRIC_L2) sh->norm_valid = h->ndev;
     return RAG_OK;
 }
 
@@ -1023,6 +1239,63 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                 rc = search_device(h, cn, q_dev + c0 * h->d, k, D_dev + c0 * k, I_dev + c0 * k, id_base, st);
                 if (rc) return rc;
             }
+            return RAG_OK;
+        }
+    }
+    // bfloat16 prefilter (rag_flat_prefilter): kp candidates per query from the shadow, exact scores from the
+    // fp32 rows, a proof per query that nothing else can rank among the top k, and the list-mode tile kernel
+    // for the queries whose proof does not close (both of its kernels return at once when there are none)
+    if (h->shadow != nullptr && !bf && plan_ok && n >= opt.prefilter_min_rows) {
+        // four candidates per wanted row: with fewer the gap between the k-th and the kp-th score is often
+        // inside the rounding margin (70k x 768 unit rows, k = 64 of 128 candidates: 23 of 33 queries redone)
+        int kp = opt.prefilter_kp > 0 ? (int)std::min<int64_t>(opt.prefilter_kp, PF_MAX_KP)
+                                      : ((nq <= 8 && k <= 16) ? 64 : PF_MAX_KP);
+        if (kp >= 4 * k || (opt.prefilter_kp > 0 && kp >= k)) {
+            rc = sync_shadow(h, st);
+            if (rc) return rc;
+            rc = grow(h->ws_pD, h->ws_pD_cap, nq * kp);
+            if (rc) return rc;
+            rc = grow(h->ws_pI, h->ws_pI_cap, nq * kp);
+            if (rc) return rc;
+            rc = grow(h->ws_key, h->ws_key_cap, nq * plan.nlists * k);
+            if (rc) return rc;
+            rc = grow(h->ws_id, h->ws_id_cap, nq * plan.nlists * k);
+            if (rc) return rc;
+            rc = grow(h->ws_cnt, h->ws_cnt_cap, 2 * nq + 1);
+            if (rc) return rc;
+            rc = prepare_l2_norms(h, qf, nq, st);
+            if (rc) return rc;
+            if (!h->zero16) {
+                RAG_HIP(hipMalloc(&h->zero16, 64));
+                RAG_HIP(hipMemsetAsync(h->zero16, 0, 64, st));
+            }
+            rc = search_device(h->shadow, nq, q_dev, kp, h->ws_pD, h->ws_pI, 0, st);
+            if (rc) return rc;
+            int* nfail = h->ws_cnt + nq;
+            int* failq = h->ws_cnt + nq + 1;
+            RAG_HIP(hipMemsetAsync(nfail, 0, sizeof(int), st));
+            const double u = 1.0 / 256.0;
+            const double eps_rel = 2.0 * u + u * u + (double)(h->d + 16) / 8388608.0;
+            const double slack = (double)(h->d + 32) / 8388608.0;
+            const size_t smem = (size_t)ld * sizeof(float);
+            const float* Xf = reinterpret_cast<const float*>(h->x);
+            if (h->metric == RAG_METRIC_IP)
+                prefilter_rescore_kernel<RAG_METRIC_IP><<<(unsigned)nq, 256, smem, st>>>(
+                    Xf, (long long)n, ld, h->d, q_dev, h->ws_pD, h->ws_pI, kp, k, h->sh_max, eps_rel, slack, D_dev, I_dev,
+                    (long long)id_base, nfail, failq);
+            else
+                prefilter_rescore_kernel<RAG_METRIC_L2><<<(unsigned)nq, 256, smem, st>>>(
+                    Xf, (long long)n, ld, h->d, q_dev, h->ws_pD, h->ws_pI, kp, k, h->sh_max, eps_rel, slack, D_dev, I_dev,
+                    (long long)id_base, nfail, failq);
+            RAG_HIP(hipGetLastError());
+            rc = mfma_launch(plan, Xf, (long long)n, ld, qf, (int)nq, k, h->metric, h->ws_key, h->ws_id, h->xnorm, h->ws_qn,
+                             h->zero16, st, nfail);
+            if (rc) return rc;
+            pick_merge(KS, h->metric)<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(h->ws_key, h->ws_id, plan.nlists, k, D_dev, I_dev,
+                                                                            (long long)id_base, k, 0, failq);
+            RAG_HIP(hipGetLastError());
+            h->last_nfail = nfail;
+            snprintf(h->last_kernel, sizeof h->last_kernel, "prefilter kp%d [%.90s]", kp, h->shadow->last_kernel);
             return RAG_OK;
         }
     }
@@ -1463,6 +1736,9 @@ void rag_flat_free(rag_flat_t* h) {
         (void)hipFree(h->ws_qb);
         (void)hipFree(h->ws_qt);
         (void)hipFree(h->ws_ticket);
+        (void)hipFree(h->sh_max);
+        (void)hipFree(h->ws_pD);
+        (void)hipFree(h->ws_pI);
         if (h->async_st) (void)hipStreamDestroy(h->async_st);
         (void)hipFree(h->ws_cvt);
         (void)hipFree(h->ws_key);
@@ -1484,7 +1760,44 @@ void rag_flat_free(rag_flat_t* h) {
         for (auto& p : h->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto& p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     }
+    if (h->shadow) rag_flat_free(h->shadow);
     delete h;
+}
+
+int rag_flat_prefilter_redone(rag_flat_t* h, int64_t* n_queries) {
+    RAG_REQUIRE_INIT();
+    if (!h || !n_queries) return fail(RAG_ERR_INVALID_ARG, "bad handle or NULL output");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *n_queries = 0;
+    if (!h->last_nfail || std::strncmp(h->last_kernel, "prefilter", 9) != 0) return RAG_OK;
+    int v = 0;
+    RAG_HIP(hipDeviceSynchronize());  // the search may still run on a caller's stream
+    RAG_HIP(hipMemcpy(&v, h->last_nfail, sizeof v, hipMemcpyDeviceToHost));
+    *n_queries = v;
+    return RAG_OK;
+}
+
+int rag_flat_prefilter(rag_flat_t* h, int enable) {
+    RAG_REQUIRE_INIT();
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "bad handle");
+    rag_flat* old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (enable) {
+            if (h->dtype != RAG_DTYPE_F32)
+                return fail(RAG_ERR_UNSUPPORTED, "rag_flat_prefilter: the index already stores bfloat16 rows");
+            if (h->shadow) return RAG_OK;
+            rag_flat_t* sh = nullptr;
+            const int rc = rag_flat_create(h->d, h->metric, RAG_DTYPE_BF16, &sh);
+            if (rc) return rc;
+            h->shadow = sh;  // rows are copied by the next search (sync_shadow)
+            return RAG_OK;
+        }
+        old = h->shadow;
+        h->shadow = nullptr;
+    }
+    if (old) rag_flat_free(old);  // waits for the device
+    return RAG_OK;
 }
 
 int rag_flat_reserve(rag_flat_t* h, int64_t n_capacity) {
@@ -1578,6 +1891,10 @@ int rag_flat_reset(rag_flat_t* h) {
     h->ntotal = 0;
     h->ndev = 0;
     h->norm_valid = 0;
+    if (h->shadow) {  // refilled from row 0 by the next search (sync_shadow)
+        h->shadow->ntotal = h->shadow->ndev = 0;
+        h->shadow->norm_valid = 0;
+    }
     return RAG_OK;
 }
 

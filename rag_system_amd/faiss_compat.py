@@ -86,6 +86,14 @@ class _HipFlatBackend:
     def reset(self):
         _lib.check(self._lib.rag_flat_reset(self._h), self._lib)
 
+    def prefilter(self, enable):
+        _lib.check(self._lib.rag_flat_prefilter(self._h, 1 if enable else 0), self._lib)
+
+    def prefilter_redone(self):
+        n = C.c_int64()
+        _lib.check(self._lib.rag_flat_prefilter_redone(self._h, C.byref(n)), self._lib)
+        return n.value
+
     def last_kernel(self):
         """Which kernels served the last search on this handle (rag_flat_last_kernel)."""
         return (self._lib.rag_flat_last_kernel(self._h) or b"").decode()
@@ -177,6 +185,12 @@ class IndexFlat:
 
     def reset(self):
         self._b.reset()
+
+    def set_prefilter(self, enable=True):
+        """Not in faiss, off by default (rag_flat_prefilter): keep a bfloat16 copy of the fp32 rows (+50 % HBM);
+        searches with k <= 32 read the copy for candidates, score them again from the fp32 rows and verify
+        per query that no other row can reach the top k -- the result is that of the fp32 rows."""
+        self._b.prefilter(enable)
 
     def reconstruct_n(self, n0=0, ni=None):
         return self._b.to_host(n0, ni)

@@ -1,0 +1,187 @@
+"""GPU parity tests of the opt-in bfloat16 prefilter of an fp32 index (rag_flat_prefilter, csrc/flat.hip).
+
+The prefilter must never change the result: candidates come from a bfloat16 copy of the rows, scores from the
+fp32 rows, and a per-query bound decides whether the candidates provably contain the top k.  Checked against
+the float64 oracle (oracle/dense.py, restating the IndexFlat.search call of vector_storage.py:196) to the same
+bar as the plain fp32 search, against that search itself, and with inputs built to defeat the bound (rows that
+differ from each other by less than a bfloat16 rounding; one row a thousand times longer than the rest; too
+few candidates), where the device-side redo on the fp32 rows has to deliver the result.
+"""
+import numpy as np
+import pytest
+
+from oracle import dense as od
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+ATOL = 2e-6
+
+
+def _rand_unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+    return x
+
+
+def _scorer(X, Q, metric):
+    X64, Q64 = X.astype(np.float64), Q.astype(np.float64)
+
+    def f(qi, ids):
+        rows = X64[ids]
+        return rows @ Q64[qi] if metric == 0 else ((rows - Q64[qi]) ** 2).sum(axis=1)
+    return f
+
+
+def _opts(lib, **kw):
+    from rag_system_amd import _lib
+    for name, val in kw.items():
+        _lib.check(lib.rag_set_option(name.encode(), val))
+
+
+def _check(idx, X, Q, k, metric, rtol=RTOL):
+    D, I = idx.search(Q, k)
+    _, Ir, D64 = od.flat_search(X, Q, k, metric)
+    od.check_topk(D, I, D64, Ir, rtol, ATOL if metric == 0 else 4e-6, _scorer(X, Q, metric))
+    return D, I
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d", [(40_000, 384), (33_001, 100), (70_003, 768), (50_000, 37)])
+def test_prefilter_equals_plain_search_and_oracle(engine, n, d, metric):
+    """Every batch size class (stream kernel 1-8, wide 9-64, chunks 65-192, tile kernel above) and k up to 32,
+    duplicated rows included (exact ties inside the candidates)."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(n + d + metric)
+    X = _rand_unit(rng, n, d)
+    X[n // 2] = X[3]
+    X[n - 1] = X[3]
+    idx = faiss.IndexFlat(d, metric)
+    idx.add(X)
+    for nq, k in [(1, 10), (1, 1), (2, 32), (8, 10), (5, 16), (9, 10), (33, 32), (64, 5), (100, 10), (300, 20)]:
+        Q = _rand_unit(rng, nq, d)
+        Q[0] = X[3]
+        idx.set_prefilter(False)
+        D0, I0 = _check(idx, X, Q, k, metric)
+        assert "prefilter" not in idx._b.last_kernel()
+        idx.set_prefilter(True)
+        D1, I1 = _check(idx, X, Q, k, metric)
+        assert idx._b.last_kernel().startswith("prefilter"), idx._b.last_kernel()
+        redone = idx._b.prefilter_redone()
+        assert redone <= 2, (nq, k, redone)   # the duplicated rows aside, random unit rows are proved at once
+        same = I0 == I1
+        # different ids only where the two fp32 scores tie to the bar
+        assert np.allclose(D0[~same], D1[~same], rtol=RTOL, atol=4e-6), (nq, k)
+        assert same.mean() > 0.99
+        assert np.allclose(D0, D1, rtol=RTOL, atol=4e-6)
+    # k > 32: served without the prefilter
+    idx.search(_rand_unit(rng, 2, d), 33)
+    assert "prefilter" not in idx._b.last_kernel()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_prefilter_rows_closer_than_a_bf16_rounding(engine, metric):
+    """20 000 rows inside a ball of relative radius 1e-3 around one direction (all of them round to nearly
+    the same bfloat16 row) plus 30 000 ordinary rows: the candidates of the copy are an arbitrary subset of the
+    cluster, the bound cannot close, and the fp32 redo has to return the true order."""
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(5 + metric)
+    d = 128
+    base = _rand_unit(rng, 1, d)
+    cluster = base + 1e-3 * rng.standard_normal((20_000, d)).astype(np.float32) / np.sqrt(d)
+    X = np.concatenate([_rand_unit(rng, 30_000, d), cluster.astype(np.float32)])
+    X = X[rng.permutation(len(X))]
+    idx = faiss.IndexFlat(d, metric)
+    idx.add(X)
+    idx.set_prefilter(True)
+    for nq, k in [(1, 10), (4, 20), (40, 10), (200, 10)]:
+        Q = _rand_unit(rng, nq, d)
+        Q[0] = base[0]
+        Q[-1] = base[0] + 0.01 * Q[-1]
+        _check(idx, X, Q, k, metric)
+        assert idx._b.last_kernel().startswith("prefilter")
+        assert idx._b.prefilter_redone() >= min(2, nq)     # at least the queries aimed at the cluster
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_prefilter_one_long_row_and_nan(engine, metric):
+    """max ||x|| enters the bound: one row 1000 times longer than the rest makes it useless (every query is
+    redone), a NaN row makes it undefined (same).  Results still exact."""
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(77 + metric)
+    d = 64
+    X = _rand_unit(rng, 40_000, d)
+    X[123] *= 1000.0
+    idx = faiss.IndexFlat(d, metric)
+    idx.add(X)
+    idx.set_prefilter(True)
+    Q = _rand_unit(rng, 5, d)
+    _check(idx, X, Q, 10, metric)
+    assert idx._b.prefilter_redone() == 5
+    Q = _rand_unit(rng, 70, d)
+    _check(idx, X, Q, 10, metric)
+    assert idx._b.prefilter_redone() == 70
+    # rows added later reach the copy too
+    X2 = _rand_unit(rng, 3_000, d)
+    X2[7] = Q[0]
+    idx.add(X2)
+    Xall = np.concatenate([X, X2])
+    D, I = _check(idx, Xall, Q, 10, metric)
+    assert I[0, 0] == 40_007 or metric == 0
+    # reset empties the copy as well
+    idx.reset()
+    Y = _rand_unit(rng, 35_000, d)
+    idx.add(Y)
+    _check(idx, Y, Q, 10, metric)
+    assert idx._b.last_kernel().startswith("prefilter")
+
+
+def test_prefilter_too_few_candidates_are_redone(engine):
+    """prefilter_kp = k: the k candidates of the copy are the only ones, so the bound closes only when the
+    k-th exact score clears the k-th approximate score by the rounding margin -- most queries are redone.
+    Either way the result is the oracle's."""
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(99)
+    d, n = 384, 60_000
+    X = _rand_unit(rng, n, d)
+    idx = faiss.IndexFlat(d, 0)
+    idx.add(X)
+    idx.set_prefilter(True)
+    try:
+        for kp, nq, k in [(10, 3, 10), (10, 50, 10), (16, 300, 16), (20, 7, 10)]:
+            _opts(lib, prefilter_kp=kp)
+            Q = _rand_unit(rng, nq, d)
+            _check(idx, X, Q, k, 0)
+            assert idx._b.last_kernel().startswith("prefilter kp%d" % kp)
+            assert idx._b.prefilter_redone() >= (nq // 2 if kp == k else 0)
+    finally:
+        _opts(lib, prefilter_kp=0)
+
+
+def test_prefilter_small_shards_and_bf16_index(engine):
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(3)
+    X = _rand_unit(rng, 5_000, 96)
+    idx = faiss.IndexFlat(96, 0)
+    idx.add(X)
+    idx.set_prefilter(True)
+    Q = _rand_unit(rng, 3, 96)
+    _check(idx, X, Q, 10, 0)
+    assert "prefilter" not in idx._b.last_kernel()      # below prefilter_min_rows
+    try:
+        _opts(lib, prefilter_min_rows=1)
+        for n in (5_000, 100, 30):                     # fewer rows than candidates: the copy returns them all
+            idx.reset()
+            idx.add(X[:n])
+            _check(idx, X[:n], Q, 10, 0)
+            assert idx._b.last_kernel().startswith("prefilter")
+            D, I = idx.search(Q, 50)                    # k > 32: direct
+            assert "prefilter" not in idx._b.last_kernel()
+    finally:
+        _opts(lib, prefilter_min_rows=32768)
+    b = faiss.IndexFlat(96, 0, storage="bf16")
+    with pytest.raises(Exception):
+        b.set_prefilter(True)
