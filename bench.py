@@ -71,6 +71,8 @@ def parse():
                     help="skip the extra batch-1024 measurement reported beside the batch-1 headline")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary-config legs (c2, c3, c4, c5)")
     ap.add_argument("--legs", default="c2,c3,c4_shard,c5", help="which secondary legs to run at N=1")
+    ap.add_argument("--prefilter", action="store_true",
+                    help="A/B: enable the opt-in bfloat16 prefilter (rag_flat_prefilter) on the index of the main run")
     ap.add_argument("--c4-rows", type=int, default=100_000_000, help="rows of the N>1 c4 leg (x 768 fp32)")
     return ap.parse_args()
 
@@ -326,6 +328,8 @@ def main():
 
     log("building the %d x %d %s index (%d rank(s))" % (n, d, args.storage, world))
     main_run = Runner(env, n, d, k, nq, args.storage, args.seed, args.out)
+    if args.prefilter:
+        main_run.index.set_prefilter(True)
     log("timing %d steps" % args.steps)
     elapsed, n_launch, scan_ms, bytes_per_launch = main_run.timed(args.steps, args.warmup)
     stages = main_run.stages() if world > 1 else None

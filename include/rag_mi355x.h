@@ -119,8 +119,8 @@ int rag_flat_search(rag_flat_t* h, int64_t nq, const float* q, int k, float* D, 
 /* Opt-in bfloat16 prefilter of an fp32 index.  No counterpart in the reference (vector_storage.py:196 is a
  * plain faiss IndexFlat search); the results stay those of the fp32 rows.  enable != 0: the index keeps a
  * bfloat16 copy of its rows (+50 % HBM, filled by the next search and kept up to date by later ones).
- * Searches with k <= 32 on shards of "prefilter_min_rows" rows or more then stream the copy for 64 (up to
- * 8 queries, k <= 16) or 128 candidates per query, score the candidates again from the fp32 rows (float64
+ * Searches with k <= 26 on shards of "prefilter_min_rows" rows or more then stream the copy for 64 (up to
+ * 8 queries, k <= 16) or 104 candidates per query, score the candidates again from the fp32 rows (float64
  * accumulation, one rounding to fp32) and check per query that no other row can reach the top k:
  * |bf16 score - exact score| <= (2^-7 + 2^-16 + (d+16) 2^-23) ||x|| ||q||.  A query whose check does not
  * close is searched again on the fp32 rows (device side, same call).  Scores may differ from the plain

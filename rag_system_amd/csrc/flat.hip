@@ -1248,8 +1248,10 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     if (h->shadow != nullptr && !bf && plan_ok && n >= opt.prefilter_min_rows) {
         // four candidates per wanted row: with fewer the gap between the k-th and the kp-th score is often
         // inside the rounding margin (70k x 768 unit rows, k = 64 of 128 candidates: 23 of 33 queries redone)
+        // (104, not 128: the list-mode tile kernel -- the redo of the copy's own filter flow -- keeps at most
+        // 109 entries per list in LDS for its 128-query block shape)
         int kp = opt.prefilter_kp > 0 ? (int)std::min<int64_t>(opt.prefilter_kp, PF_MAX_KP)
-                                      : ((nq <= 8 && k <= 16) ? 64 : PF_MAX_KP);
+                                      : ((nq <= 8 && k <= 16) ? 64 : 104);
         if (kp >= 4 * k || (opt.prefilter_kp > 0 && kp >= k)) {
             rc = sync_shadow(h, st);
             if (rc) return rc;
@@ -1269,6 +1271,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
                 RAG_HIP(hipMalloc(&h->zero16, 64));
                 RAG_HIP(hipMemsetAsync(h->zero16, 0, 64, st));
             }
+            h->shadow->prof = h->prof;
             rc = search_device(h->shadow, nq, q_dev, kp, h->ws_pD, h->ws_pI, 0, st);
             if (rc) return rc;
             int* nfail = h->ws_cnt + nq;
@@ -2141,9 +2144,23 @@ int rag_flat_timing(rag_flat_t* h, int64_t* n_launches, double* total_ms, double
         h->ev_free.push_back(p);
     }
     h->ev_used.clear();
+    double bytes = (double)h->ndev * h->d * h->esz;
+    if (h->shadow && !h->shadow->ev_used.empty()) {  // prefiltered searches: the pass over the bfloat16 copy
+        rag_flat* sh = h->shadow;
+        for (auto& p : sh->ev_used) {
+            RAG_HIP(hipEventSynchronize(p.second));
+            float ms = 0.f;
+            RAG_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+            sum += ms;
+            ++cnt;
+            sh->ev_free.push_back(p);
+        }
+        sh->ev_used.clear();
+        bytes = (double)sh->ndev * sh->d * sh->esz;
+    }
     if (n_launches) *n_launches = cnt;
     if (total_ms) *total_ms = sum;
-    if (bytes_per_launch) *bytes_per_launch = (double)h->ndev * h->d * h->esz;
+    if (bytes_per_launch) *bytes_per_launch = bytes;
     return RAG_OK;
 }
 

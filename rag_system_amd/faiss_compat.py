@@ -188,7 +188,7 @@ class IndexFlat:
 
     def set_prefilter(self, enable=True):
         """Not in faiss, off by default (rag_flat_prefilter): keep a bfloat16 copy of the fp32 rows (+50 % HBM);
-        searches with k <= 32 read the copy for candidates, score them again from the fp32 rows and verify
+        searches with k <= 26 read the copy for candidates, score them again from the fp32 rows and verify
         per query that no other row can reach the top k -- the result is that of the fp32 rows."""
         self._b.prefilter(enable)
 
