@@ -344,6 +344,13 @@ def main():
         batch_leg = rb.leg("batch1024", 5, 1, "the headline corpus, nq=1024")
         del rb
 
+    # Opt-in bfloat16 prefilter (rag_flat_prefilter; never part of `value`): the same corpus and queries with a
+    # bfloat16 copy of the rows as candidate source; results are those of the fp32 rows (compared below).
+    pf_leg = None
+    if world == 1 and nq == 1 and not bf and not args.no_batch_leg and not args.prefilter and k <= 16:
+        log("prefilter leg")
+        pf_leg = prefilter_leg(env, main_run, elapsed / args.steps * 1e3, args)
+
     out = None
     if rank == 0:
         Dn, In = main_run.check_plausible()     # outside the timed region: a plausible top-k
@@ -387,6 +394,8 @@ def main():
             out["pipelined"] = piped
         if batch_leg is not None:
             out["batch1024"] = batch_leg
+        if pf_leg is not None:
+            out["prefilter"] = pf_leg
 
     # ---- N > 1: BASELINE config 4 (north_star's scaling workload), rows split over the ranks
     if world > 1 and not args.no_legs:
@@ -448,6 +457,45 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def prefilter_leg(env, main_run, main_ms, args):
+    """The headline corpus searched through the opt-in bfloat16 prefilter: nq = 1, 64, 1024, each beside the
+    plain fp32 search of the same queries (ids compared outside the timed regions)."""
+    import numpy as np
+    idx = main_run.index
+    n, d, k = main_run.rows_total, main_run.d, main_run.k
+    legs = {}
+    plain = {1: (main_run.D_host.numpy().copy(), main_run.I_host.numpy().copy(), main_ms)}
+    for nq_, steps in ((1, 100), (64, 30), (1024, 5)):
+        r = Runner(env, n, d, k, nq_, "f32", args.seed, args.out, index=idx)
+        if nq_ not in plain:
+            idx.set_prefilter(False)
+            el0, _, _, _ = r.timed(steps, 2)
+            plain[nq_] = (r.D_host.numpy().copy(), r.I_host.numpy().copy(), el0 / steps * 1e3)
+        idx.set_prefilter(True)
+        el, nl, ms, bpl = r.timed(steps, 3)
+        redone = idx._b.prefilter_redone()
+        D1, I1 = r.check_plausible()
+        D0, I0, ms0 = plain[nq_]
+        same = I0 == I1
+        assert np.allclose(D0, D1, rtol=1e-5, atol=2e-6), "prefilter scores differ from the fp32 search"
+        assert same.mean() >= 0.999, "prefilter ids differ from the fp32 search"
+        avg = ms / max(nl, 1)
+        legs["nq%d" % nq_] = {
+            "value": nq_ * steps / el, "unit": "QPS", "steps": steps, "ms_per_step": el / steps * 1e3,
+            "plain_fp32_ms_per_step": ms0, "queries_redone_last_step": redone,
+            "ids_identical_to_plain_search": float(same.mean()),
+            "copy_pass": {"kernel": idx._b.last_kernel(), "avg_launch_ms": avg, "launches": nl,
+                          "bytes_per_launch": bpl, "GB/s": bpl / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
+                          "TFLOP/s": 2.0 * nq_ * n * d / (avg * 1e-3) / 1e12 if avg > 0 else 0.0}}
+        del r
+    idx.set_prefilter(False)
+    return {"workload": "the headline corpus with rag_flat_prefilter on: candidates (64 / 104 per query) from a "
+                        "bfloat16 copy of the rows (+%.2f GB of HBM), exact scores from the fp32 rows, per-query "
+                        "proof that no other row can reach the top %d (else a device-side fp32 redo)" % (n * d * 2 / 1e9, k),
+            "note": "opt-in, off in every other number of this line; not a reduced-precision result: D / I are "
+                    "those of the fp32 rows (tests/test_prefilter_gpu.py)", **legs}
 
 
 def c5_leg(n_queries=40):

@@ -660,13 +660,14 @@ __global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restric
 }
 
 constexpr int PF_MAX_KP = 128;
+constexpr int PF_THREADS = 1024;  // 16 waves: a wave scores 4-8 candidates, each a dependent trip to HBM (4 waves: 26 us per call, 16: 9)
 
 // One workgroup per query.  pD / pI: the shadow's kp best rows (approximate scores, local ids, -1 = none).
 // Exact scores: float64 accumulation over the fp32 row, rounded once to fp32 (L2: sum of (x - q)^2).
 // Writes the exact top k (ties: lower id first) to D / I and flags the query (failq = 1, ++nfail) when
 // the bound above does not close.
 template <int METRIC>
-__global__ __launch_bounds__(256) void prefilter_rescore_kernel(
+__global__ __launch_bounds__(PF_THREADS) void prefilter_rescore_kernel(
     const float* __restrict__ X, long long n, int ld, int d, const float* __restrict__ Q,
     const float* __restrict__ pD, const long long* __restrict__ pI, int kp, int k,
     const unsigned int* __restrict__ max_bits, double eps_rel, double slack, float* __restrict__ D,
@@ -676,13 +677,13 @@ __global__ __launch_bounds__(256) void prefilter_rescore_kernel(
     __shared__ float s_e[PF_MAX_KP];               // exact score, same sense
     __shared__ int s_id[PF_MAX_KP];
     __shared__ unsigned char s_need[PF_MAX_KP];
-    __shared__ double s_red[2][4];
+    __shared__ double s_red[2][PF_THREADS / 64];
     __shared__ double s_L, s_B;
     __shared__ float s_Ek;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* qrow = Q + (long long)q * d;
     double qq = 0.0, qqb = 0.0;
-    for (int c = tid; c < ld; c += 256) {
+    for (int c = tid; c < ld; c += PF_THREADS) {
         const float v = c < d ? qrow[c] : 0.0f;
         s_q[c] = v;
         const float vb = __uint_as_float((unsigned int)bf16_rne(v) << 16);
@@ -703,8 +704,11 @@ __global__ __launch_bounds__(256) void prefilter_rescore_kernel(
         s_Ek = __builtin_nanf("");
     }
     __syncthreads();
-    qq = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
-    qqb = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    qq = qqb = 0.0;
+    for (int w = 0; w < PF_THREADS / 64; ++w) {
+        qq += s_red[0][w];
+        qqb += s_red[1][w];
+    }
     const double mx2 = (double)__uint_as_float(*max_bits);
     double eps = eps_rel * sqrt(mx2 * qq);
     if (METRIC == RAG_METRIC_L2) eps = 2.0 * eps + slack * (mx2 + qq);  // + the fp32 roundings of both norms and of the key
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(256) void prefilter_rescore_kernel(
     const bool need = valid && (a + eps >= s_L);
     if (tid < kp) s_need[tid] = need;
     const int m = __syncthreads_count(need);
-    for (int i = wid; i < kp; i += 4) {
+    for (int i = wid; i < kp; i += PF_THREADS / 64) {
         if (!s_need[i]) continue;
         const f32x4* row = reinterpret_cast<const f32x4*>(X + (long long)s_id[i] * ld);
         const f32x4* qv = reinterpret_cast<const f32x4*>(s_q);
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(256) void prefilter_rescore_kernel(
         }
         if (r == kk - 1) s_Ek = e;
     }
-    for (int pos = (m < k ? m : k) + tid; pos < k; pos += 256) {
+    for (int pos = (m < k ? m : k) + tid; pos < k; pos += PF_THREADS) {
         D[(long long)q * k + pos] = METRIC == RAG_METRIC_IP ? -FLT_MAX : FLT_MAX;
         I[(long long)q * k + pos] = -1;
     }
@@ -1283,11 +1287,11 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
             const size_t smem = (size_t)ld * sizeof(float);
             const float* Xf = reinterpret_cast<const float*>(h->x);
             if (h->metric == RAG_METRIC_IP)
-                prefilter_rescore_kernel<RAG_METRIC_IP><<<(unsigned)nq, 256, smem, st>>>(
+                prefilter_rescore_kernel<RAG_METRIC_IP><<<(unsigned)nq, PF_THREADS, smem, st>>>(
                     Xf, (long long)n, ld, h->d, q_dev, h->ws_pD, h->ws_pI, kp, k, h->sh_max, eps_rel, slack, D_dev, I_dev,
                     (long long)id_base, nfail, failq);
             else
-                prefilter_rescore_kernel<RAG_METRIC_L2><<<(unsigned)nq, 256, smem, st>>>(
+                prefilter_rescore_kernel<RAG_METRIC_L2><<<(unsigned)nq, PF_THREADS, smem, st>>>(
                     Xf, (long long)n, ld, h->d, q_dev, h->ws_pD, h->ws_pI, kp, k, h->sh_max, eps_rel, slack, D_dev, I_dev,
                     (long long)id_base, nfail, failq);
             RAG_HIP(hipGetLastError());

@@ -650,7 +650,11 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     // wave of a SIMD also carries every list insert); filter pass nq 4 k 100: 2.318 against 2.354.
     // 1M rows: nq 1 k 10 0.240 against 0.246 ms; nq 4 k 30 0.307 against 0.265 (list warm-up)
     const long long list_load = nq * (long long)k;
-    const bool light_auto = filt || (list_load <= 64 && (n >= (4LL << 20) || list_load <= 16));
+    // rows of up to three 256-byte segments (384 bfloat16 values: the copy of rag_flat_prefilter): a tile is over
+    // after three steps and the epilogue's fold + inserts stall a ring of two (10M x 384 bf16, nq 1, k 64:
+    // 1.354 ms with the light shape, 1.086 with the deep ring = 7.07 TB/s; benchmarks/run_prefilter_opts.sh)
+    const bool short_rows = dch <= 48;
+    const bool light_auto = !short_rows && (filt || (list_load <= 64 && (n >= (4LL << 20) || list_load <= 16)));
     p->NB = light_built && (opt.stream_nb == NB_LIGHT || (opt.stream_nb == 0 && light_auto)) ? NB_LIGHT : NB_DEFAULT;
     const int NB = p->NB;
     const int dchp = ((dch + 16 * NB - 1) / (16 * NB)) * (16 * NB);
