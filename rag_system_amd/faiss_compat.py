@@ -190,7 +190,8 @@ class IndexFlat:
         """Not in faiss, off by default (rag_flat_prefilter): keep a bfloat16 copy of the fp32 rows (+50 % HBM);
         searches with k <= 26 read the copy for candidates, score them again from the fp32 rows and verify
         per query that no other row can reach the top k -- the result is that of the fp32 rows."""
-        self._b.prefilter(enable)
+        if hasattr(self._b, "prefilter"):      # (test backends that are exact anyway have none)
+            self._b.prefilter(enable)
 
     def reconstruct_n(self, n0=0, ni=None):
         return self._b.to_host(n0, ni)

@@ -81,6 +81,15 @@ class VectorStorage:
         self.chunks_data = []
         self._tfidf_scorer = None
         self._tfidf_scorer_key = None
+        self._dense_prefilter = False
+
+    def set_dense_prefilter(self, enable=True):
+        """Not in the reference, off by default: the dense index keeps a bfloat16 copy of its rows as candidate
+        source for searches with top_k <= 26 (faiss_compat.IndexFlat.set_prefilter / rag_flat_prefilter).  The
+        hits are those of the fp32 rows; +50 % HBM for the index.  Survives rebuild_faiss_index."""
+        self._dense_prefilter = bool(enable)
+        if hasattr(self.index, "set_prefilter"):
+            self.index.set_prefilter(self._dense_prefilter)
 
     def set_chunk_params(self, chunk_size, overlap):
         self.chunk_size = chunk_size
@@ -143,6 +152,8 @@ class VectorStorage:
 
     def rebuild_faiss_index(self, embedding_manager):
         self.index = faiss.IndexFlatIP(self.embedding_dim)
+        if self._dense_prefilter:
+            self.index.set_prefilter(True)
         if not self.chunks_data:
             return
         texts = [cd["chunk"] for cd in self.chunks_data]

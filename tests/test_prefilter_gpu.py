@@ -227,3 +227,33 @@ def test_prefilter_full_size_10M_x_384(engine):
         assert same.mean() > 0.999, (nq, same.mean())          # ids differ only between fp32 near-ties
     if nq >= 3:
         assert I1[nq - 1, 0] == 0 and I1[nq - 1, 1] == n, "duplicate of row 0 must follow it (lower id first)"
+
+
+def test_vector_storage_dense_prefilter_same_hits(engine):
+    """VectorStorage.set_dense_prefilter: the hits of search / search_batch are those of the plain store, also
+    after rebuild-style re-creation of the index (the switch is kept)."""
+    from rag_system_amd import _lib
+    from rag_system_amd.vector_storage import VectorStorage
+    lib = _lib.engine()
+    rng = np.random.default_rng(21)
+    d, n = 64, 3000
+    X = _rand_unit(rng, n, d)
+    vs = VectorStorage(d)
+    for i in range(n):
+        vs.add_vector(X[i], "doc%d" % (i // 7), "chunk %d" % i, source="s")
+    Q = _rand_unit(rng, 5, d)
+    plain = [vs.search(q, top_k=5) for q in Q]
+    plain_b = vs.search_batch(Q, top_k=5)
+    try:
+        _opts(lib, prefilter_min_rows=1)
+        vs.set_dense_prefilter(True)
+        got = [vs.search(q, top_k=5) for q in Q]
+        assert vs.index._b.last_kernel().startswith("prefilter")
+        got_b = vs.search_batch(Q, top_k=5)
+        tok = vs.search_begin(Q[0], top_k=5)
+        got_be = vs.search_end(tok)
+    finally:
+        _opts(lib, prefilter_min_rows=32768)
+    for a, b in zip(plain + plain_b + [plain[0]], got + got_b + [got_be]):
+        assert [h["chunk"] for h in a] == [h["chunk"] for h in b]
+        assert np.allclose([h["score"] for h in a], [h["score"] for h in b], rtol=1e-5, atol=2e-6)
