@@ -29,32 +29,25 @@ constexpr int MMR_SMALL_C = 64;
 // Up to RRF_LDS_T entries (every call the search engine makes: three rankings of <= 9*top_k entries) the
 // ids, ranks and first-occurrence table live in LDS: the O(T^2) comparisons never leave the CU, and the
 // inputs may then sit in pinned HOST memory -- they are read exactly once, coalesced -- so that a call
-// is one launch and one synchronisation with no copies.  Larger T: the same code on the HBM copies.
+// is one launch and one synchronisation with no copies.  Larger T: rrf_sort_kernel below.
 constexpr int RRF_LDS_T = 2048;
-template <bool LDS>
 __global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __restrict__ ids_g,
                                                            const int* __restrict__ rank_g, int T, double k_const,
                                                            long long* __restrict__ out_ids,
-                                                           double* __restrict__ out_scores, int* __restrict__ n_out,
-                                                           int* __restrict__ first_g) {
+                                                           double* __restrict__ out_scores, int* __restrict__ n_out) {
     __shared__ int s_count[CAND_THREADS / 64];
-    __shared__ long long s_ids[LDS ? RRF_LDS_T : 1];
-    __shared__ int s_rank[LDS ? RRF_LDS_T : 1];
-    __shared__ int s_first[LDS ? RRF_LDS_T : 1];
+    __shared__ long long s_ids[RRF_LDS_T];
+    __shared__ int s_rank[RRF_LDS_T];
+    __shared__ int s_first[RRF_LDS_T];
     const int tid = threadIdx.x;
-    const long long* ids = ids_g;
-    const int* rank_of = rank_g;
-    int* first = first_g;
-    if (LDS) {
-        for (int e = tid; e < T; e += CAND_THREADS) {
-            s_ids[e] = ids_g[e];
-            s_rank[e] = rank_g[e];
-        }
-        __syncthreads();
-        ids = s_ids;
-        rank_of = s_rank;
-        first = s_first;
+    for (int e = tid; e < T; e += CAND_THREADS) {
+        s_ids[e] = ids_g[e];
+        s_rank[e] = rank_g[e];
     }
+    __syncthreads();
+    const long long* ids = s_ids;
+    const int* rank_of = s_rank;
+    int* first = s_first;
     for (int e = tid; e < T; e += CAND_THREADS) {
         const long long id = ids[e];
         int f = e;
@@ -101,6 +94,111 @@ __global__ __launch_bounds__(CAND_THREADS) void rrf_kernel(const long long* __re
         for (int j = e; j < T; ++j)
             if (ids[j] == id) s = s + 1.0 / (k_const + (double)rank_of[j]);
         out_ids[o] = id;
+        out_scores[o] = s;
+        ++o;
+    }
+}
+
+// 2048 < T <= 16384 entries (top_k in the hundreds): the quadratic table above would take a millisecond.
+// Here every id gets the entry number of its first occurrence through a hash table in LDS (open addressing;
+// a slot belongs to the id that claimed it, its value is the smallest entry number seen for that id), the keys
+// (first occurrence << 14 | entry) are sorted in LDS, and a sorted run of equal first occurrences is one
+// distinct id with its entries in input order: the same sums in the same order as Python's dictionary
+// (search_engine.py:352-359), output in first-appearance order.  O(T log^2 T / 1024) per thread, and a run is
+// walked by one thread (all entries the same id: T additions, as before).
+constexpr int RRF_HASH_SLOTS = 32768;  // >= 2 * RRF_MAX_ENTRIES; 128 KiB of LDS, reused for the <= 16384 sort keys
+__global__ __launch_bounds__(CAND_THREADS) void rrf_sort_kernel(const long long* __restrict__ ids,
+                                                                const int* __restrict__ rank_of, int T, double k_const,
+                                                                long long* __restrict__ out_ids,
+                                                                double* __restrict__ out_scores, int* __restrict__ n_out,
+                                                                int* __restrict__ slot_of) {
+    extern __shared__ unsigned int sm[];
+    __shared__ int s_count[CAND_THREADS / 64];
+    const int tid = threadIdx.x;
+    int* table = reinterpret_cast<int*>(sm);
+    for (int i = tid; i < RRF_HASH_SLOTS; i += CAND_THREADS) table[i] = INT_MAX;
+    __syncthreads();
+    for (int e = tid; e < T; e += CAND_THREADS) {
+        const long long id = ids[e];
+        unsigned int slot = (unsigned int)(((unsigned long long)id * 0x9E3779B97F4A7C15ULL) >> 49);  // 15 bits
+        for (;;) {
+            int cur = table[slot];
+            if (cur == INT_MAX) {
+                cur = atomicCAS(&table[slot], INT_MAX, e);
+                if (cur == INT_MAX) break;  // claimed for this id
+            }
+            if (ids[cur] == id) {           // (whichever entry of the owner is recorded right now: the same id)
+                atomicMin(&table[slot], e);
+                break;
+            }
+            slot = (slot + 1) & (RRF_HASH_SLOTS - 1);
+        }
+        slot_of[e] = (int)slot;
+    }
+    __syncthreads();
+    unsigned int mykey[RRF_MAX_ENTRIES / CAND_THREADS];
+#pragma unroll
+    for (int u = 0; u < RRF_MAX_ENTRIES / CAND_THREADS; ++u) {
+        const int e = tid + u * CAND_THREADS;
+        mykey[u] = e < T ? ((unsigned int)table[slot_of[e]] << 14) | (unsigned int)e : 0xFFFFFFFFu;
+    }
+    __syncthreads();  // the table is dead: its LDS becomes the key array
+    int N = 2048;
+    while (N < T) N <<= 1;
+#pragma unroll
+    for (int u = 0; u < RRF_MAX_ENTRIES / CAND_THREADS; ++u) {
+        const int e = tid + u * CAND_THREADS;
+        if (e < N) sm[e] = mykey[u];
+    }
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            for (int p = tid; p < N / 2; p += CAND_THREADS) {
+                const int i = ((p & ~(st - 1)) << 1) | (p & (st - 1));
+                const int jx = i + st;
+                const bool asc = (i & size) == 0;
+                const unsigned int a = sm[i], b = sm[jx];
+                if (asc ? a > b : a < b) {
+                    sm[i] = b;
+                    sm[jx] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // a run starts where entry == first occurrence; contiguous span of sorted positions per thread
+    const int per = (T + CAND_THREADS - 1) / CAND_THREADS;
+    const int lo = tid * per, hi = min(T, lo + per);
+    int cnt = 0;
+    for (int p = lo; p < hi; ++p) cnt += (sm[p] >> 14) == (sm[p] & 16383u);
+    const int lane = tid & 63, wid = tid >> 6;
+    int incl = cnt;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const int y = __shfl_up(incl, dd);
+        if (lane >= dd) incl += y;
+    }
+    if (lane == 63) s_count[wid] = incl;
+    __syncthreads();
+    if (wid == 0) {
+        constexpr int NW = CAND_THREADS / 64;
+        const int w = lane < NW ? s_count[lane] : 0;
+        int ws = w;
+        for (int dd = 1; dd < NW; dd <<= 1) {
+            const int y = __shfl_up(ws, dd);
+            if (lane >= dd) ws += y;
+        }
+        if (lane < NW) s_count[lane] = ws - w;
+        if (lane == NW - 1) *n_out = ws;
+    }
+    __syncthreads();
+    int o = s_count[wid] + incl - cnt;
+    for (int p = lo; p < hi; ++p) {
+        const unsigned int f = sm[p] >> 14;
+        if (f != (sm[p] & 16383u)) continue;
+        double s = 0.0;
+        for (int pp = p; pp < T && (sm[pp] >> 14) == f; ++pp)
+            s = s + 1.0 / (k_const + (double)rank_of[sm[pp] & 16383u]);
+        out_ids[o] = ids[f];
         out_scores[o] = s;
         ++o;
     }
@@ -393,17 +491,22 @@ int rag_rrf(int n_rankings, const int64_t* ids, const int64_t* lens, double k_co
     char* dfirst = dout + out_b;
     if (T <= RRF_LDS_T) {
         // the kernel reads the pinned inputs once into LDS and writes the results to pinned memory: no copies
-        rrf_kernel<true><<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<long long*>(hin), reinterpret_cast<int*>(hin + ids_b),
-                                                    (int)T, k_const, reinterpret_cast<long long*>(hout + 8),
-                                                    reinterpret_cast<double*>(hout + 8 + ids_b),
-                                                    reinterpret_cast<int*>(hout), nullptr);
+        rrf_kernel<<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<long long*>(hin), reinterpret_cast<int*>(hin + ids_b),
+                                               (int)T, k_const, reinterpret_cast<long long*>(hout + 8),
+                                               reinterpret_cast<double*>(hout + 8 + ids_b), reinterpret_cast<int*>(hout));
         RAG_HIP(hipGetLastError());
     } else {
         RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
-        rrf_kernel<false><<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<long long*>(din), reinterpret_cast<int*>(din + ids_b),
-                                                     (int)T, k_const, reinterpret_cast<long long*>(dout + 8),
-                                                     reinterpret_cast<double*>(dout + 8 + ids_b),
-                                                     reinterpret_cast<int*>(dout), reinterpret_cast<int*>(dfirst));
+        static bool attr_set = false;  // under ws.mu
+        if (!attr_set) {
+            RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rrf_sort_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, RRF_HASH_SLOTS * 4));
+            attr_set = true;
+        }
+        rrf_sort_kernel<<<1, CAND_THREADS, RRF_HASH_SLOTS * 4, st>>>(
+            reinterpret_cast<long long*>(din), reinterpret_cast<int*>(din + ids_b), (int)T, k_const,
+            reinterpret_cast<long long*>(dout + 8), reinterpret_cast<double*>(dout + 8 + ids_b), reinterpret_cast<int*>(dout),
+            reinterpret_cast<int*>(dfirst));
         RAG_HIP(hipGetLastError());
         RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
     }

@@ -20,30 +20,33 @@
 //     CU moves such an instruction at 58 B/clk from the L2 and ANY multi-row shape (8 x 128 B, 16 x 64
 //     B, 4 x 256 B) at 31 B/clk (benchmarks/glds_pattern.hip), and half of this kernel's LDS fill is
 //     queries.  (The rows stay row-major: every other kernel reads that layout.)
-// (2) The schedule inside a stage: the two wave groups of the block (wm = 0 / 1, one wave of each
-//     per SIMD) alternate.  flat_mfma_kernel has all eight waves issue their loads, read their
-//     fragments and multiply at the same time, so the matrix pipe idles while every wave of a SIMD
-//     sits in load issue (an LDS-DMA instruction costs its wave 60-185 cycles) or waits for the
-//     LDS.  Here a stage is two phases per group, and the second group runs one barrier behind:
+// (2) The schedule inside a stage.  flat_mfma_kernel has all eight waves issue their loads, read their
+//     fragments and multiply one after the other, so the matrix pipe idles while every wave of a SIMD
+//     sits in load issue (an LDS-DMA instruction costs its wave 60-185 cycles) or waits for the LDS.
+//     Here a stage is four K slices, each one batch of 8 MFMAs (32x32x16 bf16; fp32: 32 of 32x32x2)
+//     whose operands were read from the LDS during the batch before (two fragment sets, fa / fb, filled
+//     alternately by inline-assembly ds_read_b128 that the compiler's wait insertion does not see), and
+//     the stage's eight LDS-DMA instructions are spread over the batches, two per batch, behind the
+//     second and the sixth MFMA:
 //
-//       group 0:  mem A | mul A | mem B | mul B | mem A' | ...
-//       group 1:        | mem A | mul A | mem B | mul B  | ...       ("|" = s_barrier of all 8 waves)
+//       batch 1 (slice 0 of stage e):  reads of slice 1 in flight | loads: queries of stage e+1, second half
+//       batch 2 (slice 1):             reads of slice 2           | loads: rows of stage e+2, first half
+//       batch 3 (slice 2):             reads of slice 3           | loads: rows of stage e+2, second half
+//       s_waitcnt vmcnt(4) lgkmcnt(0); s_barrier      (own loads of stage e+1 landed, all reads of e returned)
+//       batch 4 (slice 3):             reads of slice 0 of e+1    | loads: queries of stage e+2, first half
+//       [once per row tile: the filter epilogue]
 //
-//     mem A: fragments of K slices 0,1 of stage e -> registers (12 ds_read_b128); LDS-DMA of the
-//            queries of stage e+1 (4 instructions); own reads returned (lgkmcnt(0))
-//     mul A: 16 MFMAs (32x32x16 bf16; fp32: 64 of 32x32x2) at raised priority
-//     mem B: slices 2,3; LDS-DMA of the rows of stage e+2; own loads of stage e+1 landed
-//            (vmcnt(4): all but the four just issued), own reads returned
-//     mul B: 16 MFMAs; behind its closing barrier, once per row tile, the filter epilogue (VALU work
-//            that runs beside the other group's MFMAs)
+//     One barrier per stage; all waits are counted (vmcnt(4): everything but the four row loads just
+//     issued).  Tried and measured slower or equal: the two wave groups a phase apart ("ping-pong"),
+//     different load slots per SIMD, four dedicated loader waves.
 //
-// Safety of the rings.  Write after read: the loads of mem A(e) / mem B(e) go into the buffers stage
-// e-1 used; the last reads of stage e-1 are group 1's in its mem B(e-1), which end (lgkmcnt(0))
-// before the barrier that group 0 passes on its way into mem A(e).  Read after write: stage e+1 is
-// first read in group 0's mem A(e+1), behind the barrier that closes its mul B(e); every wave waited
-// for its own loads of stage e+1 in its mem B(e), which ends at the barrier before that one (group
-// 0) or at that barrier itself (group 1).  K order per accumulator is the same as in
-// flat_mfma_kernel, so the scores are bit-identical.
+// Safety of the rings.  Write after read: the loads issued during stage e go into the row buffer and the
+// query buffer that stage e-1 used (rows: ring of three, two stages ahead; queries: the half issued in
+// batch 1 goes to the buffer of stage e-1, whose last reads returned before the barrier of stage e-1; the
+// half issued in batch 4, behind the barrier of stage e, goes to the buffer stage e itself used, whose
+// reads all returned before that barrier).  Read after write: stage e+1 is first read behind the barrier
+// of stage e, and every wave waited for its own loads of stage e+1 in front of that barrier.  K order per
+// accumulator is the same as in flat_mfma_kernel, so the scores are bit-identical.
 #pragma once
 
 namespace rag {

@@ -158,6 +158,28 @@ def test_rrf_matches_reference_restatement(engine):
     assert reciprocal_rank_fusion([[], []]) == {}
 
 
+def test_rrf_large_candidate_sets(engine):
+    """More than 2048 ranking entries (top_k in the hundreds) take the hash + sort kernel (rrf_sort_kernel):
+    same dictionary, same order, same float64 bits; few distinct ids with long runs, all ids distinct, a single
+    id, the 16384-entry limit, and the limit exceeded."""
+    import time
+    from rag_system_amd.candidates import reciprocal_rank_fusion
+    from rag_system_amd._lib import EngineError
+    rng = np.random.default_rng(43)
+    for npool, lens in [(5000, (1500, 1400, 1300)), (40, (900, 800, 700)), (100000, (5000, 5000, 5000)),
+                        (1, (3000,)), (3000, (16384,)), (9000, (5461, 5461, 5462)), (2049, (2049,)), (700, (2000, 49))]:
+        rankings = [[int(i) for i in rng.integers(0, npool, L)] for L in lens]
+        exp = ofu.reciprocal_rank_fusion([[(d, 0.0) for d in r] for r in rankings], k=60)
+        t0 = time.perf_counter()
+        got = reciprocal_rank_fusion(rankings, k=60)
+        ms = (time.perf_counter() - t0) * 1e3
+        assert list(got.keys()) == list(exp.keys()), (npool, lens)
+        assert [_bits(v) for v in got.values()] == [_bits(v) for v in exp.values()], (npool, lens)
+        print("rrf T=%d distinct=%d: %.2f ms" % (sum(lens), len(exp), ms))
+    with pytest.raises((EngineError, ValueError)):
+        reciprocal_rank_fusion([list(range(16385))], k=60)
+
+
 def test_mmr_selection_matches_reference_restatement(engine):
     """search_engine.py:396-468 incl. the max_context_bytes branch (:457-463: a pick the budget rejects
     is dropped without being selected, and the loop goes on).  A selection that differs from the
