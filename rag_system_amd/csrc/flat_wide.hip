@@ -2,8 +2,8 @@
 // rows streamed from HBM straight into 16x16 MFMA operands, no LDS staging of the matrix and no
 // barrier after the queries are in LDS -- every wave runs its own load -> multiply pipeline.
 //
-// Same reference loop as flat.hip / flat_stream.hip (vector_storage.py:257-271 IndexFlat.search,
-// :159-195 Python fallback), for the batch sizes where neither the
+// Same reference call as flat.hip / flat_stream.hip (index.search(q, k), vector_storage.py:196, on the
+// faiss IndexFlatIP built at :79 / :146 / :151), for the batch sizes where neither the
 // 4x4 stream kernel (query operands re-read from LDS per 4 rows) nor the LDS tile kernel (load,
 // LDS and MFMA phases in lock step: 5.8 ms for 64 queries over 10M x 384 against 3.1 ms of matrix
 // math) is near a roofline.

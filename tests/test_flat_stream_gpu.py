@@ -1,8 +1,8 @@
 """GPU parity tests of the register-fed small-batch kernel (csrc/flat_stream.hip): batches of
 1..16 queries, k <= 128, list mode and filter mode.
 
-Checked against the float64 oracle (oracle/dense.py, restating vector_storage.py:159-195 and the
-IndexFlat.search call at :257-271) to the fp32 bar of BASELINE.json (1e-5 relative, ids identical
+Checked against the float64 oracle (oracle/dense.py, restating the IndexFlat.search call at
+vector_storage.py:196) to the fp32 bar of BASELINE.json (1e-5 relative, ids identical
 except near-ties), and against the tile kernel it replaces for these batch sizes.
 """
 import numpy as np

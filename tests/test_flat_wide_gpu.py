@@ -1,8 +1,7 @@
 """GPU parity tests of the 16x16 register-fed batch kernel (csrc/flat_wide.hip): 17..64 queries,
 sample pass (wave maxima -> threshold) + filter pass + exact selection, redo by the tile kernel.
 
-Oracle: float64 restatement of vector_storage.py:159-195 / the IndexFlat.search call at :257-271
-(oracle/dense.py); bar: 1e-5 relative, ids identical except near-ties (BASELINE.json).
+Oracle: float64 restatement of the IndexFlat.search call at vector_storage.py:196 (oracle/dense.py); bar: 1e-5 relative, ids identical except near-ties (BASELINE.json).
 """
 import numpy as np
 import pytest
