@@ -41,6 +41,7 @@ struct WidePlan {
     int cap;          // filter pass: entries per query in the append buffer
     int sample_step;  // sample pass: every sample_step-th 16-row tile
     int blocks, wpb;  // grid, waves per block
+    int nb;           // ring depth (step buffers per wave): 3 or 4
     int wpad;         // sample pass output entries per query (= blocks)
     size_t smem;
 };

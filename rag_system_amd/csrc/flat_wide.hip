@@ -54,7 +54,7 @@ __host__ __device__ constexpr int wide_nb(int NT) { return RAG_WIDE_NB_HI > 0 &&
 __host__ __device__ inline int wide_nstep(int dch, int nb) { return ((dch + 8 * nb - 1) / (8 * nb)) * nb; }
 
 // n >= 16.  cand_*: SAMPLE [nq][wpad] (one entry per block), FILTER [nq][cap].
-template <int NT, int METRIC, bool BF, bool SAMPLE>
+template <int NT, int METRIC, bool BF, bool SAMPLE, int NB>
 __global__ __launch_bounds__(NT >= 3 ? 768 : WIDE_MAX_THREADS) void flat_wide_kernel(
     const u32x4* __restrict__ X, long long n, int dch, const u32x4* __restrict__ Q, int nq,
     float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
@@ -67,7 +67,6 @@ __global__ __launch_bounds__(NT >= 3 ? 768 : WIDE_MAX_THREADS) void flat_wide_ke
     const int nwv = blockDim.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const bool hi8 = (lane & 8) != 0;
-    constexpr int NB = wide_nb(NT);
     const int nstep = wide_nstep(dch, NB);
     const int npair = nstep * 4;            // chunk pairs per (padded) row
     const int plane = NT * npair * 16;      // u32x4 per plane (even / odd chunks)
@@ -304,11 +303,11 @@ __global__ __launch_bounds__(NT >= 3 ? 768 : WIDE_MAX_THREADS) void flat_wide_ke
     }
 }
 
-template <int NT, bool BF, bool SAMPLE>
-int launch(const WidePlan& p, const void* X, long long n, int dch, const void* Q, int nq, int metric, float* cand_key,
-           int* cand_id, const float* xnorm, const float* qnorm, const float* thr_q, unsigned int* counts, hipStream_t st) {
-    auto fn = metric == RAG_METRIC_IP ? flat_wide_kernel<NT, RAG_METRIC_IP, BF, SAMPLE>
-                                      : flat_wide_kernel<NT, RAG_METRIC_L2, BF, SAMPLE>;
+template <int NT, bool BF, bool SAMPLE, int NB>
+int launch_nb(const WidePlan& p, const void* X, long long n, int dch, const void* Q, int nq, int metric, float* cand_key,
+              int* cand_id, const float* xnorm, const float* qnorm, const float* thr_q, unsigned int* counts, hipStream_t st) {
+    auto fn = metric == RAG_METRIC_IP ? flat_wide_kernel<NT, RAG_METRIC_IP, BF, SAMPLE, NB>
+                                      : flat_wide_kernel<NT, RAG_METRIC_L2, BF, SAMPLE, NB>;
     if (p.smem > 48 * 1024)
         RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p.smem));
@@ -317,6 +316,17 @@ int launch(const WidePlan& p, const void* X, long long n, int dch, const void* Q
         (long long)(SAMPLE ? p.sample_step : 1), thr_q, counts, p.cap, p.wpad);
     RAG_HIP(hipGetLastError());
     return RAG_OK;
+}
+
+// the ring of the plan: the default depth of the tile count, or 3 where up to two query tiles ask for it
+template <int NT, bool BF, bool SAMPLE>
+int launch(const WidePlan& p, const void* X, long long n, int dch, const void* Q, int nq, int metric, float* cand_key,
+           int* cand_id, const float* xnorm, const float* qnorm, const float* thr_q, unsigned int* counts, hipStream_t st) {
+    if constexpr (NT <= 2 && wide_nb(NT) != 3) {
+        if (p.nb == 3)
+            return launch_nb<NT, BF, SAMPLE, 3>(p, X, n, dch, Q, nq, metric, cand_key, cand_id, xnorm, qnorm, thr_q, counts, st);
+    }
+    return launch_nb<NT, BF, SAMPLE, wide_nb(NT)>(p, X, n, dch, Q, nq, metric, cand_key, cand_id, xnorm, qnorm, thr_q, counts, st);
 }
 
 template <bool SAMPLE>
@@ -353,7 +363,15 @@ bool wide_plan(long long n, long long nq, int dch, bool bf16, int j, int cap, in
     p->bf16 = bf16;
     p->cap = cap;
     p->sample_step = sample_step < 1 ? 1 : sample_step;
-    const int nstep = wide_nstep(dch, wide_nb(p->NT));
+    // Ring depth: rows are padded to a multiple of NB 128-byte steps.  Up to two query tiles the default is 4;
+    // rows of 6 steps (384 bfloat16 values -- the copy of rag_flat_prefilter) then run 8.  The padding steps are
+    // cheap (their loads re-read a cached chunk), so the shorter ring only pays with two query tiles (10M x 384
+    // bf16: 32 queries 1.319 ms against 1.381, 16 queries 1.439 against 1.399; benchmarks/run_prefilter_mid.sh).
+    p->nb = wide_nb(p->NT);
+    if (p->NT == 2 && wide_nstep(dch, 3) < wide_nstep(dch, p->nb)) p->nb = 3;
+    if (opt.wide_nb == 3 && p->NT <= 2) p->nb = 3;
+    if (opt.wide_nb == 4 && p->NT <= 2) p->nb = 4;
+    const int nstep = wide_nstep(dch, p->nb);
     p->smem = (size_t)2 * p->NT * nstep * 4 * 16 * 16;
     if (p->smem > 160 * 1024) return false;  // long rows: the tile kernel streams its queries instead
     // Waves per CU the register budget admits (launch bounds of the kernel): 24 for one query tile,
