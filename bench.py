@@ -187,7 +187,8 @@ class Runner:
             self.index._b.search_dev(nq, qp, kk, dp, ip, self.base, st)
 
         self.searcher = ShardedFlatSearcher(local_search, 0, nq, k, dev, stream=stream,
-                                            out=self.out_host if out_mode == "pinned" else None)
+                                            out=self.out_host if out_mode == "pinned" else None,
+                                            force_exchange=env.get("force_exchange", False))
         self.D_host, self.I_host = self.searcher.unpack(self.out_host)
 
     def step(self):
@@ -317,12 +318,19 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    # RAG_BENCH_FORCE_EXCHANGE=1 (N = 1 only): a one-rank RCCL group, and every step takes the all-gather +
+    # merge path of N > 1 -- what the exchange step costs on the real transport before a second GPU exists
+    force_exchange = world == 1 and os.environ.get("RAG_BENCH_FORCE_EXCHANGE") == "1"
+    if force_exchange:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ.get("MASTER_PORT", "29533"),
+                                rank=0, world_size=1, device_id=dev)
     lib = _lib.engine(dev_index)
     for o in args.opt:
         name, val = o.split("=")
         _lib.check(lib.rag_set_option(name.encode(), int(val)))
 
-    env = {"world": world, "rank": rank, "dev": dev, "stream": torch.cuda.Stream(dev)}
+    env = {"world": world, "rank": rank, "dev": dev, "stream": torch.cuda.Stream(dev), "force_exchange": force_exchange}
     n, d, k, nq = args.rows, args.dim, args.k, args.nq
     bf = args.storage == "bf16"
 
@@ -332,8 +340,8 @@ def main():
         main_run.index.set_prefilter(True)
     log("timing %d steps" % args.steps)
     elapsed, n_launch, scan_ms, bytes_per_launch = main_run.timed(args.steps, args.warmup)
-    stages = main_run.stages() if world > 1 else None
-    piped = main_run.pipelined(args.steps) if (world == 1 and args.out == "pinned") else None
+    stages = main_run.stages() if (world > 1 or force_exchange) else None
+    piped = main_run.pipelined(args.steps) if (world == 1 and args.out == "pinned" and not force_exchange) else None
 
     # The metric has two halves (batch 1 and batch 1024).  `value` is the batch-1 half; the other
     # is measured right after it on the same resident corpus (not part of `value`).
@@ -377,7 +385,8 @@ def main():
             "value": qps, "unit": "QPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16" if bf else "f32",
-            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else ""),
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else "")
+                    + (" (one-rank RCCL group, every step through the all-gather + merge path of N > 1)" if force_exchange else ""),
             "config": {"workload": "%d x %d %s L2-normalised synthetic rows (seed %d), IndexFlatIP top-%d, nq=%d"
                                    % (n, d, "bf16" if bf else "fp32", args.seed, k, nq),
                        "rows": n, "dim": d, "k": k, "nq": nq, "storage": args.storage,
@@ -456,6 +465,7 @@ def main():
 
     if world > 1:
         dist.barrier()
+    if world > 1 or force_exchange:
         dist.destroy_process_group()
 
 

@@ -65,7 +65,8 @@ class ShardedFlatSearcher:
         m = nq * k
         return m + (m + 1) // 2
 
-    def __init__(self, local_search, metric, nq, k, device, group=None, merge=None, stream=None, out=None):
+    def __init__(self, local_search, metric, nq, k, device, group=None, merge=None, stream=None, out=None,
+                 force_exchange=False):
         import torch
         import torch.distributed as dist
         self._torch = torch
@@ -84,7 +85,10 @@ class ShardedFlatSearcher:
         if out is not None:
             assert out.dtype == torch.int64 and out.numel() == words and out.is_contiguous()
         self._stage = False
-        if self.world > 1:
+        # force_exchange: take the all-gather + merge path with ONE rank too (a rehearsal of the collective's
+        # stream ordering and buffer layout on a one-GPU box: tests/test_sharded_rccl_gpu.py)
+        self.exchange = self.world > 1 or bool(force_exchange)
+        if self.exchange:
             self._pack = torch.zeros(words, dtype=torch.int64, device=device)
             self._pack_all = torch.zeros((self.world, words), dtype=torch.int64, device=device)
             self.I_all = self._pack_all[:, :m].view(self.world, nq, k)
@@ -131,7 +135,7 @@ class ShardedFlatSearcher:
         torch = self._torch
         # one rank and no stage timing: nothing of torch's is enqueued here (local_search gets the stream's
         # handle explicitly), so the current-stream switch, a few microseconds per call, is skipped
-        need_ctx = self.on_gpu and self.stream is not None and (self.world > 1 or self.stage_events)
+        need_ctx = self.on_gpu and self.stream is not None and (self.exchange or self.stage_events)
         ctx = torch.cuda.stream(self.stream) if need_ctx else contextlib.nullcontext()
         with ctx:
             st = self._handle()
@@ -141,7 +145,7 @@ class ShardedFlatSearcher:
             self.local_search(q, self.k, self.D_loc, self.I_loc, st)
             if ev:
                 ev[1].record()
-            if self.world > 1:
+            if self.exchange:
                 if self._stage:
                     self._h_pack.copy_(self._pack, non_blocking=True)
                     torch.cuda.current_stream().synchronize()
@@ -173,7 +177,7 @@ class ShardedFlatSearcher:
                 (self.stream or torch.cuda.current_stream()).synchronize()
                 ev = self.stage_events
                 acc[0] += ev[0].elapsed_time(ev[1])
-                if self.world > 1:
+                if self.exchange:
                     acc[1] += ev[1].elapsed_time(ev[2])
                     acc[2] += ev[2].elapsed_time(ev[3])
         finally:
