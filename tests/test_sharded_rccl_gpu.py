@@ -23,6 +23,7 @@ def _free_port():
     return p
 
 
+@pytest.mark.timeout(240, method="thread")
 def test_one_rank_rccl_exchange_equals_local_search(engine):
     import torch
     import torch.distributed as dist
