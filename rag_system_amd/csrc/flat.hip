@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restric
 }
 
 constexpr int PF_MAX_KP = 128;
-constexpr int PF_THREADS = 1024;  // 16 waves: a wave scores 4-8 candidates, each a dependent trip to HBM (4 waves: 26 us per call, 16: 9)
+constexpr int PF_THREADS = 1024;  // 16 waves x 4 candidates: one round for 64 candidates
 
 // One workgroup per query.  pD / pI: the shadow's kp best rows (approximate scores, local ids, -1 = none).
 // Exact scores: float64 accumulation over the fp32 row, rounded once to fp32 (L2: sum of (x - q)^2).
@@ -741,24 +741,28 @@ __global__ __launch_bounds__(PF_THREADS) void prefilter_rescore_kernel(
     const bool need = valid && (a + eps >= s_L);
     if (tid < kp) s_need[tid] = need;
     const int m = __syncthreads_count(need);
-    for (int i = wid; i < kp; i += PF_THREADS / 64) {
-        if (!s_need[i]) continue;
-        const f32x4* row = reinterpret_cast<const f32x4*>(X + (long long)s_id[i] * ld);
-        const f32x4* qv = reinterpret_cast<const f32x4*>(s_q);
+    // sixteen lanes per candidate, four candidates per wave, all 64 of a round at once: every load of a row is
+    // independent of the others, so a round costs one trip to HBM (one wave per candidate, one after the other: four)
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (int i = wid * 4 + sub; i < kp; i += PF_THREADS / 16) {
         double acc = 0.0;
-        for (int c = lane; c < ld / 4; c += 64) {
-            const f32x4 x = row[c], y = qv[c];
+        if (s_need[i]) {
+            const f32x4* row = reinterpret_cast<const f32x4*>(X + (long long)s_id[i] * ld);
+            const f32x4* qv = reinterpret_cast<const f32x4*>(s_q);
+            for (int c = l16; c < ld / 4; c += 16) {
+                const f32x4 x = row[c], y = qv[c];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (METRIC == RAG_METRIC_IP) acc += (double)x[e] * (double)y[e];
-                else {
-                    const double df = (double)x[e] - (double)y[e];
-                    acc += df * df;
+                for (int e = 0; e < 4; ++e) {
+                    if (METRIC == RAG_METRIC_IP) acc += (double)x[e] * (double)y[e];
+                    else {
+                        const double df = (double)x[e] - (double)y[e];
+                        acc += df * df;
+                    }
                 }
             }
         }
-        for (int dist = 32; dist >= 1; dist >>= 1) acc += __shfl_xor(acc, dist);
-        if (lane == 0) s_e[i] = METRIC == RAG_METRIC_IP ? (float)acc : -(float)acc;
+        for (int dist = 8; dist >= 1; dist >>= 1) acc += __shfl_xor(acc, dist);
+        if (l16 == 0 && s_need[i]) s_e[i] = METRIC == RAG_METRIC_IP ? (float)acc : -(float)acc;
     }
     __syncthreads();
     if (need) {
