@@ -162,9 +162,6 @@ __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const fl
             const int l = tid + u * ST_THREADS;
             if (l < N4) hv[l] = key[u][0];
         }
-#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 2
-        return;
-#endif
         if (tid == 0) {
             *n_cand = 0;
             *T_s = -FLT_MAX;  // fewer than k lists: everything is a candidate
@@ -187,9 +184,6 @@ __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const fl
         }
         __syncthreads();
         const float T = *T_s;
-#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 3
-        return;
-#endif
 #pragma unroll
         for (int u = 0; u < FUSE_LPT; ++u) {
             // sorted: the entries >= T are a prefix; ONE counter update per list that has any
@@ -209,9 +203,6 @@ __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const fl
         }
         __syncthreads();
         const int cnt = *n_cand;
-#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 4
-        return;
-#endif
         if (cnt <= FUSE_CAP) {  // uniform
             // place by rank: the composites are distinct (ids are), so the ranks are a permutation
             for (int i = tid; i < cnt; i += ST_THREADS) {
@@ -553,9 +544,6 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
     __syncthreads();
     if (*last == 0) return;
     __syncthreads();  // *last is read by everyone before the merge reuses the LDS
-#if defined(RAG_FUSE_ABL) && RAG_FUSE_ABL == 1
-    return;
-#endif
     stream_fused_merge<METRIC>(smem_raw, cand_key, cand_id, (int)gridDim.x, nq, k, D, I, id_base);
 }
 
