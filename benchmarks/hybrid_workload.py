@@ -8,7 +8,7 @@ dense rows from the engine's generator (seed 1234), queries seed 4321.
 Per query (search_engine.py:320-350 with top_k = 10):
     dense   index.search(q, 9*top_k)  -> first 3*top_k distinct documents     (rag_flat_search)
     bm25    top 3*top_k chunks                                                 (rag_bm25_scores)
-    tfidf   scores of all documents; top (top_k + |A|) + ranks of A            (rag_tfidf_query)
+    tfidf   scores of all documents; top (top_k + |A|) + ranks of A            (rag_tfidf_query_begin / _end)
     rrf     1/(60+rank) over the three rankings                                (rag_rrf)
     mmr     top_k of the fused top 3*top_k, stored vectors as embeddings       (rag_mmr)
 
@@ -98,6 +98,10 @@ class HybridWorkload:
         t0 = time.perf_counter()
         # search_faiss(document mode, 3*top_k) begun, search_bm25(3*top_k) beside it, as search_engine.search_rrf does
         pending = self.index.search_begin(self.Qd[qi:qi + 1], 9 * top_k)
+        t1a = time.perf_counter()
+        # TF-IDF scoring begun too (search_engine._tfidf_begin): it needs the query only; its rank query follows the fusion
+        uq, cnt = np.unique(tids, return_counts=True)
+        tf_tok = self.ts.ranks_from_row_begin(uq, cnt * self.tfidf_idf[uq], 7 * top_k)
         t1 = time.perf_counter()
         bI, bD = self.bm.top_k(raw, 3 * top_k)
         bm_rank = [int(i) for i in bI]
@@ -109,10 +113,12 @@ class HybridWorkload:
         t3 = time.perf_counter()
         # TF-IDF: every document is ranked (search_engine.py:332-336); only the candidates and
         # the head of the ranking can reach the fused top_k (rag_system_amd/search_engine.py)
-        uq, cnt = np.unique(tids, return_counts=True)
         cand = list(fused)
-        tI, tD, ranks = self.ts.ranks_from_row(uq, cnt * self.tfidf_idf[uq], top_k + len(cand),
-                                               np.asarray(cand, dtype=np.int64))
+        if tf_tok is not None:
+            tI, tD, ranks = self.ts.ranks_from_row_end(tf_tok, top_k + len(cand), np.asarray(cand, dtype=np.int64))
+        else:
+            tI, tD, ranks = self.ts.ranks_from_row(uq, cnt * self.tfidf_idf[uq], top_k + len(cand),
+                                                   np.asarray(cand, dtype=np.int64))
         t4 = time.perf_counter()
         for doc, rk in zip(cand, ranks):
             fused[doc] = fused[doc] + 1.0 / (60 + int(rk))
@@ -128,9 +134,9 @@ class HybridWorkload:
         t6 = time.perf_counter()
         emb = self.embeddings(ids) if keep_emb else None
         if tsum is not None:
-            tsum["dense"] += (t1 - t0) + (t2 - t2a)      # enqueue + what was left to wait for
+            tsum["dense"] += (t1a - t0) + (t2 - t2a)     # enqueue + what was left to wait for
             tsum["bm25"] += t2a - t1                      # (runs beside the dense pass)
-            tsum["tfidf"] += t4 - t3
+            tsum["tfidf"] += (t1 - t1a) + (t4 - t3)       # enqueue of the scoring + the rank query behind the fusion
             tsum["rrf"] += (t3 - t2) + (t5 - t4)
             tsum["mmr"] += t6 - t5b
             tsum["total"] += (t6 - t0) - (t5b - t5)

@@ -247,6 +247,16 @@ int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_s
  * to the three calls. */
 int rag_tfidf_query(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights, int k, double* D,
                     int64_t* I, int n_query, const int64_t* rows, int64_t* ranks, double* row_scores);
+/* rag_tfidf_query in two halves, for the caller that knows the query before it knows the rows it wants ranked:
+ * search_engine.py:330-336 scores the query against the TF-IDF matrix and sorts ALL documents after the dense
+ * and the BM25 rankings are in; the scoring does not depend on them.  _begin enqueues scoring and the top-k
+ * selection (k = an upper bound) on the handle's own stream and returns; _end waits for it, delivers the first
+ * k (<= the bound) entries of the ranking and then ranks / gathers `rows` from the score vector left in HBM
+ * (three short launches, one synchronisation).  One begun query per handle; other calls on the handle are
+ * refused until _end.  RAG_ERR_UNSUPPORTED when the one-launch scoring path does not serve the index or k. */
+int rag_tfidf_query_begin(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights, int k);
+int rag_tfidf_query_end(rag_csc_t* h, int k, double* D, int64_t* I, int n_query, const int64_t* rows, int64_t* ranks,
+                        double* row_scores);
 
 /* ---- candidate-set kernels -------------------------------------------- */
 

@@ -86,6 +86,8 @@ SIGNATURES = {
     "rag_csc_ranks": (C.c_int, [_p, C.c_int, _p, _p]),
     "rag_csc_gather": (C.c_int, [_p, C.c_int, _p, _p]),
     "rag_tfidf_query": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, _p, _p, C.c_int, _p, _p, _p]),
+    "rag_tfidf_query_begin": (C.c_int, [_p, C.c_int, _p, _p, C.c_int]),
+    "rag_tfidf_query_end": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, _p, _p, _p]),
     "rag_rrf": (C.c_int, [C.c_int, _p, _p, C.c_double, _p, _p, _p]),
     "rag_mmr": (C.c_int, [C.c_int, C.c_int, _p, _p, C.c_double, C.c_int, _p, _i64, _p, _p]),
     "rag_flat_mmr": (C.c_int, [_p, C.c_int, _p, _p, C.c_double, C.c_int, _p, _i64, _p, _p]),

@@ -96,6 +96,33 @@ class _HipCsc:
         return D[:k], I[:k], ranks, sc
 
 
+    def tfidf_query_begin(self, term_ids, weights, k):
+        """First half of tfidf_query (rag_tfidf_query_begin): scoring and the top-k selection enqueued on the
+        handle's own stream.  Returns False when the engine's one-launch path does not serve this index / k
+        (nothing is begun then: call tfidf_query)."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        rc = self._lib.rag_tfidf_query_begin(self._h, len(t), _lib.ptr(t), _lib.ptr(w), int(k))
+        if rc == _lib.RAG_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc, self._lib)
+        return True
+
+    def tfidf_query_abort(self):
+        """Ends a begun query without reading anything (error paths)."""
+        self._lib.rag_tfidf_query_end(self._h, 0, None, None, 0, None, None, None)
+
+    def tfidf_query_end(self, k, rows, want_scores=True):
+        """Second half: (D, I, ranks, row_scores) as tfidf_query, k <= the k the query was begun with."""
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        _, D, I = self._out(False, k)
+        ranks = np.empty(len(r), dtype=np.int64)
+        sc = np.empty(len(r), dtype=np.float64) if want_scores else None
+        _lib.check(self._lib.rag_tfidf_query_end(self._h, int(k), _lib.ptr(D), _lib.ptr(I), len(r), _lib.ptr(r),
+                                                 _lib.ptr(ranks), _lib.ptr(sc)), self._lib)
+        return D[:k], I[:k], ranks, sc
+
+
 _csc_factory = _HipCsc
 
 

@@ -349,13 +349,15 @@ __device__ __forceinline__ bool pair_ahead(double ka, long long ia, double kb, l
 __global__ __launch_bounds__(RANK_MAXQ) void rank_prep_kernel(const double* __restrict__ score, int nq,
                                                               const long long* __restrict__ qrow,
                                                               double* __restrict__ skey, long long* __restrict__ srow,
-                                                              int* __restrict__ pos_of, unsigned long long* __restrict__ hist) {
+                                                              int* __restrict__ pos_of, unsigned long long* __restrict__ hist,
+                                                              double* __restrict__ gather_out = nullptr) {
     __shared__ double ks[RANK_MAXQ];
     __shared__ long long rs[RANK_MAXQ];
     const int i = threadIdx.x;
     if (i < nq) {
         rs[i] = qrow[i];
         ks[i] = score[qrow[i]];
+        if (gather_out != nullptr) gather_out[i] = ks[i];  // rag_tfidf_query_end: the queried rows' scores (pinned memory)
     }
     if (i < nq) hist[i] = 0;
     if (i == 0) hist[nq] = 0;
@@ -1058,6 +1060,9 @@ struct rag_csc {
     std::vector<int> ft_of_term;    // term -> row of the skip table, -1: rare
     double* wmax = nullptr;         // [nblk * SP_SUB] maxima of the 64-row spans
     double* bmax = nullptr;         // [nblk] maxima of the row blocks
+    // rag_tfidf_query_begin / _end: the handle's own stream, the k of the begun query (0 = none begun)
+    hipStream_t own_st = nullptr;
+    int begun_k = 0;
     std::mutex mu;
 };
 
@@ -1355,6 +1360,10 @@ int rag_csc_create(int64_t n_terms, int64_t n_rows, const int64_t* indptr, const
 void rag_csc_free(rag_csc_t* h) {
     if (!h) return;
     if (lib_stream()) (void)hipStreamSynchronize(lib_stream());
+    if (h->own_st) {
+        (void)hipStreamSynchronize(h->own_st);
+        (void)hipStreamDestroy(h->own_st);
+    }
     (void)hipFree(h->row);
     (void)hipFree(h->val);
     (void)hipFree(h->score);
@@ -1448,6 +1457,7 @@ int rag_bm25_scores(rag_csc_t* h, int n_qterms, const int32_t* term_ids, double*
     if (!h || n_qterms < 0 || (n_qterms > 0 && !term_ids) || k < 0 || (k > 0 && (!D || !I)))
         return fail(RAG_ERR_INVALID_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "a TF-IDF query is begun on this handle: end it first (rag_tfidf_query_end)");
     if (!h->bm25) return fail(RAG_ERR_INVALID_ARG, "rag_bm25_set has not been called on this handle");
     for (int i = 0; i < n_qterms; ++i)
         if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
@@ -1461,6 +1471,7 @@ int rag_tfidf_scores(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const dou
     if (!h || nnz_q < 0 || (nnz_q > 0 && (!term_ids || !q_weights)) || k < 0 || (k > 0 && (!D || !I)))
         return fail(RAG_ERR_INVALID_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "a TF-IDF query is begun on this handle: end it first (rag_tfidf_query_end)");
     for (int i = 0; i < nnz_q; ++i)
         if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
             return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
@@ -1477,6 +1488,7 @@ int rag_tfidf_query(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const doub
         return fail(RAG_ERR_INVALID_ARG, "rag_tfidf_query: n_query=%d beyond %d (use rag_csc_ranks / rag_csc_gather)",
                     n_query, RANK_MAXQ);
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "a TF-IDF query is begun on this handle: end it first (rag_tfidf_query_end)");
     for (int i = 0; i < nnz_q; ++i)
         if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
             return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
@@ -1547,10 +1559,79 @@ int rag_tfidf_query(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const doub
     return RAG_OK;
 }
 
+int rag_tfidf_query_begin(rag_csc_t* h, int nnz_q, const int32_t* term_ids, const double* q_weights, int k) {
+    RAG_REQUIRE_INIT();
+    if (!h || nnz_q < 0 || (nnz_q > 0 && (!term_ids || !q_weights)) || k < 1) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "rag_tfidf_query_begin: a query is already begun on this handle");
+    for (int i = 0; i < nnz_q; ++i)
+        if (term_ids[i] < 0 || term_ids[i] >= h->n_terms)
+            return fail(RAG_ERR_INVALID_ARG, "query term id %d outside [0,%lld)", term_ids[i], (long long)h->n_terms);
+    int G = 0;
+    if (!(h->fused && options().sparse_fused != 0) || !fused_select_ok(h, k, &G))
+        return fail(RAG_ERR_UNSUPPORTED, "rag_tfidf_query_begin: the one-launch scoring path does not serve this index or k=%d "
+                                         "(use rag_tfidf_query)", k);
+    if (!h->own_st) RAG_HIP(hipStreamCreateWithFlags(&h->own_st, hipStreamNonBlocking));
+    hipStream_t st = h->own_st;
+    // earlier calls on this handle ran on the library stream and were synchronised there before they returned
+    int rc = launch_fused_scores(h, false, nnz_q, term_ids, q_weights, 0, G, k, st);
+    if (rc) return rc;
+    rc = launch_fused_select(h, k, G, 0, false, false, st);
+    if (rc) return rc;
+    h->begun_k = k;
+    return RAG_OK;
+}
+
+int rag_tfidf_query_end(rag_csc_t* h, int k, double* D, int64_t* I, int n_query, const int64_t* rows, int64_t* ranks,
+                        double* row_scores) {
+    RAG_REQUIRE_INIT();
+    if (!h || k < 0 || (k > 0 && (!D || !I)) || n_query < 0 || (n_query > 0 && !rows))
+        return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->begun_k) return fail(RAG_ERR_INVALID_ARG, "rag_tfidf_query_end: no query begun on this handle");
+    const int kb = h->begun_k;
+    hipStream_t st = h->own_st;
+    RAG_HIP(hipStreamSynchronize(st));
+    h->begun_k = 0;
+    if (k > kb) return fail(RAG_ERR_INVALID_ARG, "rag_tfidf_query_end: k=%d beyond the %d the query was begun with", k, kb);
+    if (n_query > RANK_MAXQ)
+        return fail(RAG_ERR_INVALID_ARG, "rag_tfidf_query_end: n_query=%d beyond %d", n_query, RANK_MAXQ);
+    for (int i = 0; i < n_query; ++i)
+        if (rows[i] < 0 || rows[i] >= h->n_rows)
+            return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)rows[i], (long long)h->n_rows);
+    if (*reinterpret_cast<volatile int*>(h->pin + PIN_FLAG) != 0) {  // selection buffer overflow: list kernels
+        const int rc = topk_scores(h, kb, D, I, st);
+        if (rc) return rc;
+        RAG_HIP(hipStreamSynchronize(st));
+    }
+    topk_finish(h, k, D, I);  // the first k of the kb best: a prefix of the same stable ranking
+    const bool want_ranks = n_query > 0 && ranks != nullptr, want_scores = n_query > 0 && row_scores != nullptr;
+    if (!want_ranks && !want_scores) return RAG_OK;
+    // rank query over the score vector the begun launch left in HBM: rows read from, ranks and scores written to
+    // pinned memory by the kernels themselves (three launches, one synchronisation, no copies)
+    std::memcpy(h->pin + PIN_Q_ROWS, rows, (size_t)n_query * sizeof(long long));
+    const long long* qrows = reinterpret_cast<const long long*>(h->pin + PIN_Q_ROWS);
+    long long nb = (h->n_rows + 2047) / 2048;
+    nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
+    rank_prep_kernel<<<1, RANK_MAXQ, 0, st>>>(h->score, n_query, qrows, h->rk_skey, h->rk_srow, h->rk_pos, h->rk_hist,
+                                              reinterpret_cast<double*>(h->pin + PIN_Q_SCORES));
+    if (want_ranks) {
+        rank_hist_kernel<<<(unsigned)nb, 256, 0, st>>>(h->score, (long long)h->n_rows, n_query, h->rk_skey, h->rk_srow, h->rk_hist);
+        rank_final_kernel<<<1, RANK_MAXQ, 0, st>>>(h->rk_hist, n_query, h->rk_pos,
+                                                   reinterpret_cast<unsigned long long*>(h->pin + PIN_Q_RANKS));
+    }
+    RAG_HIP(hipGetLastError());
+    RAG_HIP(hipStreamSynchronize(st));
+    if (want_ranks) std::memcpy(ranks, h->pin + PIN_Q_RANKS, (size_t)n_query * sizeof(long long));
+    if (want_scores) std::memcpy(row_scores, h->pin + PIN_Q_SCORES, (size_t)n_query * sizeof(double));
+    return RAG_OK;
+}
+
 int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks) {
     RAG_REQUIRE_INIT();
     if (!h || n_query < 0 || (n_query > 0 && (!rows || !ranks))) return fail(RAG_ERR_INVALID_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "a TF-IDF query is begun on this handle: end it first (rag_tfidf_query_end)");
     if (!h->have_scores) return fail(RAG_ERR_INVALID_ARG, "no score vector has been computed on this handle");
     for (int i = 0; i < n_query; ++i)
         if (rows[i] < 0 || rows[i] >= h->n_rows)
@@ -1579,6 +1660,7 @@ int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_s
     RAG_REQUIRE_INIT();
     if (!h || n_query < 0 || (n_query > 0 && (!rows || !out_scores))) return fail(RAG_ERR_INVALID_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "a TF-IDF query is begun on this handle: end it first (rag_tfidf_query_end)");
     if (!h->have_scores) return fail(RAG_ERR_INVALID_ARG, "no score vector has been computed on this handle");
     for (int i = 0; i < n_query; ++i)
         if (rows[i] < 0 || rows[i] >= h->n_rows)

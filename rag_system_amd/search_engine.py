@@ -227,7 +227,29 @@ class SearchEngine:
 
     # ------------------------------------------------------------------ TF-IDF access
 
-    def _tfidf_for_candidates(self, query, cand_doc_ids, n_extra):
+    def _tfidf_begin(self, query, k_bound):
+        """Enqueue the TF-IDF scoring of `query` (rag_tfidf_query_begin) so that it runs beside the dense pass
+        and the BM25 scoring: the reference scores TF-IDF after both (search_engine.py:330-331), but the scores
+        depend on the query alone.  Returns a token for _tfidf_for_candidates, or None (nothing begun)."""
+        try:
+            scorer = self.vector_storage.get_tfidf_scorer()
+            begin = getattr(scorer, "query_begin", None)
+            if scorer is None or begin is None:
+                return None
+            tok = begin(query, k_bound)
+            return None if tok is None else (scorer, tok)
+        except Exception as e:
+            self._debug("TF-IDF begin failed: %s" % e)
+            return None
+
+    def _tfidf_abort(self, begun):
+        if begun is not None:
+            try:
+                begun[0].query_abort(begun[1])
+            except Exception:
+                pass
+
+    def _tfidf_for_candidates(self, query, cand_doc_ids, n_extra, begun=None):
         """Score the query against the HBM TF-IDF index once and return
         (top_ids, top_scores): the first `n_extra` documents of the stable descending ranking,
         (cand_rank, cand_score): TF-IDF rank / score of every candidate doc id that is indexed.
@@ -239,6 +261,7 @@ class SearchEngine:
             self._debug("get_tfidf_scorer failed: %s" % e)
             scorer, doc_ids = None, []
         if scorer is None:
+            self._tfidf_abort(begun)
             return None
         pos = getattr(self.vector_storage, "_tfidf_pos", None)
         if pos is None or pos[0] is not doc_ids or len(pos[1]) != len(doc_ids):
@@ -246,7 +269,12 @@ class SearchEngine:
             self.vector_storage._tfidf_pos = pos
         pos = pos[1]
         rows = [pos[d] for d in cand_doc_ids if d in pos]
-        top_idx, top_sc, ranks, scores = scorer.query(query, min(n_extra, len(doc_ids)), rows)
+        k = min(n_extra, len(doc_ids))
+        if begun is not None and begun[0] is scorer and k <= begun[1][1] and rows:
+            top_idx, top_sc, ranks, scores = scorer.query_end(begun[1], k, rows)
+        else:
+            self._tfidf_abort(begun)
+            top_idx, top_sc, ranks, scores = scorer.query(query, k, rows)
         cand = {doc_ids[r]: (int(rk), float(sc)) for r, rk, sc in zip(rows, ranks, scores)}
         return [doc_ids[int(i)] for i in top_idx], [float(s) for s in top_sc], cand
 
@@ -254,11 +282,16 @@ class SearchEngine:
 
     def search_multi_representation(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
         pending = self._search_faiss_begin(query, top_k * 3, "document")
-        bm25_hits = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")   # beside the dense pass
-        dense = {d["doc_id"]: d["score"] for d in self._search_faiss_end(pending)}
+        tf_begun = self._tfidf_begin(query, top_k * 7)     # beside the dense pass, like the BM25 scoring below
+        try:
+            bm25_hits = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+            dense = {d["doc_id"]: d["score"] for d in self._search_faiss_end(pending)}
+        except Exception:
+            self._tfidf_abort(tf_begun)
+            raise
         bm25 = {d["doc_id"]: d["score"] for d in bm25_hits}
         cand_ids = list(dict.fromkeys(list(dense) + list(bm25)))
-        tf = self._tfidf_for_candidates(query, cand_ids, top_k + len(cand_ids))
+        tf = self._tfidf_for_candidates(query, cand_ids, top_k + len(cand_ids), tf_begun)
         tfidf = {}
         tfidf_max = None
         if tf is not None:
@@ -292,10 +325,15 @@ class SearchEngine:
 
     def search_rrf(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
         pending = self._search_faiss_begin(query, top_k * 3, "document")
-        bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")   # beside the dense pass
-        dense_ranking = self._search_faiss_end(pending)
-        fused = self.reciprocal_rank_fusion(dense_ranking, bm25_ranking, k=60)
-        tf = self._tfidf_for_candidates(query, list(fused), top_k + len(fused))
+        tf_begun = self._tfidf_begin(query, top_k * 7)     # beside the dense pass, like the BM25 scoring below
+        try:
+            bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+            dense_ranking = self._search_faiss_end(pending)
+            fused = self.reciprocal_rank_fusion(dense_ranking, bm25_ranking, k=60)
+        except Exception:
+            self._tfidf_abort(tf_begun)
+            raise
+        tf = self._tfidf_for_candidates(query, list(fused), top_k + len(fused), tf_begun)
         if tf is not None:
             top_ids, _top_sc, cand = tf
             for doc_id in fused:                       # candidates: their own rank among ALL documents

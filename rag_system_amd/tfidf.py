@@ -114,3 +114,43 @@ class TfidfScorer:
         t, w = self._query(query)
         D, I, ranks, sc = fused(t, w, k, doc_indices)
         return I, D, ranks, sc
+
+    # ---- the same in two halves (rag_tfidf_query_begin / _end): scoring needs only the query ------------
+
+    def _begin_row(self, t, w, k_bound):
+        k_bound = min(int(k_bound), self.n_docs)
+        begin = getattr(self._csc, "tfidf_query_begin", None)
+        if begin is None or k_bound < 1 or k_bound > _bm25.BM25Okapi.MAX_FUSED_K or not begin(t, w, k_bound):
+            return None
+        return k_bound
+
+    def query_begin(self, query, k_bound):
+        """Enqueue the scoring of `query` and the selection of its k_bound best documents; returns a token for
+        query_end, or None when the engine cannot split the call (use query())."""
+        t, w = self._query(query)
+        kb = self._begin_row(t, w, k_bound)
+        return None if kb is None else ("tfidf-begun", kb)
+
+    def query_end(self, token, k, doc_indices):
+        """(top_idx, top_scores, ranks, scores) as query(query, k, doc_indices); k <= the bound given to
+        query_begin, len(doc_indices) <= MAX_QUERY_ROWS."""
+        kb = token[1]
+        k = min(int(k), self.n_docs, kb)
+        if len(doc_indices) > getattr(self._csc, "MAX_QUERY_ROWS", 0):   # more rows than one rank query takes
+            D, I, _, _ = self._csc.tfidf_query_end(k, [])
+            return I, D, self.ranks(doc_indices), self.gather(doc_indices)
+        D, I, ranks, sc = self._csc.tfidf_query_end(k, doc_indices)
+        return I, D, ranks, sc
+
+    def query_abort(self, token):
+        """Give up a begun query (the handle accepts other calls again)."""
+        self._csc.tfidf_query_abort()
+
+    def ranks_from_row_begin(self, indices, data, k_bound):
+        t, w = self._normalize_row(indices, data)
+        kb = self._begin_row(t, w, k_bound)
+        return None if kb is None else ("tfidf-begun", kb)
+
+    def ranks_from_row_end(self, token, k, doc_indices):
+        D, I, ranks, _ = self._csc.tfidf_query_end(min(int(k), self.n_docs, token[1]), doc_indices, want_scores=False)
+        return I, D, ranks

@@ -309,6 +309,53 @@ def test_csc_large_single_term_and_many_rows(engine):
         h.tfidf_query([0], [1.0], 10, np.array([n], dtype=np.int64))
 
 
+def test_tfidf_query_in_two_halves_equals_one_call(engine):
+    """rag_tfidf_query_begin / _end: the scoring enqueued on the handle's own stream, the head of the ranking
+    and the rank query delivered later -- bit-identical to rag_tfidf_query, also with a smaller k at the end,
+    beside a BM25 scoring on another handle, with 1024 queried rows, after an abort; the handle refuses other
+    calls while a query is begun."""
+    from rag_system_amd.bm25 import make_csc
+    rng = np.random.default_rng(67)
+    n, nt = 300_000, 50
+    df = rng.integers(200, 60_000, nt)
+    indptr = np.concatenate([[0], np.cumsum(df)]).astype(np.int64)
+    rows = np.concatenate([np.sort(rng.choice(n, int(c), replace=False)) for c in df]).astype(np.int32)
+    vals = rng.random(len(rows)) + 0.01
+    h = make_csc(nt, n, indptr, rows, vals)
+    other = make_csc(nt, n, indptr, rows, vals)
+    n_split = 0
+    for trial in range(8):
+        t = rng.choice(nt, int(rng.integers(1, 8)), replace=False).astype(np.int32)
+        w = rng.random(len(t))
+        q = rng.integers(0, n, int(rng.choice([1, 37, 1024]))).astype(np.int64)
+        kb = int(rng.choice([10, 70, 200]))
+        k = int(rng.integers(1, kb + 1))
+        D0, I0, rk0, rs0 = h.tfidf_query(t, w, k, q)
+        if not h.tfidf_query_begin(t, w, kb):
+            assert kb == 200                          # more than the one-launch selection serves here: nothing begun
+            h.tfidf_query(t, w, k, q)
+            continue
+        n_split += 1
+        with pytest.raises(Exception):
+            h.tfidf_query(t, w, k, q)                 # refused while begun
+        with pytest.raises(Exception):
+            h.tfidf_query_begin(t, w, kb)
+        other.tfidf_scores(t, w, want_scores=False, k=5)   # another handle works beside it (library stream)
+        D1, I1, rk1, rs1 = h.tfidf_query_end(k, q)
+        assert I1.tolist() == I0.tolist() and np.array_equal(_bits(D1), _bits(D0))
+        assert rk1.tolist() == rk0.tolist() and np.array_equal(_bits(rs1), _bits(rs0))
+    assert n_split >= 3
+    with pytest.raises(Exception):
+        h.tfidf_query_end(5, q)                       # nothing begun
+    assert h.tfidf_query_begin(t, w, 50)
+    with pytest.raises(Exception):
+        h.tfidf_query_end(51, q)                      # beyond the bound: refused, and the query is over
+    assert h.tfidf_query_begin(t, w, 50)
+    h.tfidf_query_abort()
+    D2, I2, rk2, rs2 = h.tfidf_query(t, w, k, q)      # the handle is usable again
+    assert I2.tolist() == I0.tolist() and rk2.tolist() == rk0.tolist()
+
+
 def _topk_of_vector(h_cache, scores, k):
     """Top-k of an arbitrary float64 vector through the TF-IDF entry point: one term present in
     every row with val = the vector and query weight 1.0 gives score == val bit for bit."""
