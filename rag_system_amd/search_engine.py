@@ -118,6 +118,15 @@ class SearchEngine:
             r["score"] = float(r["score"])
         return hits
 
+    def _dense_abort(self, token):
+        """A stage between the two halves raised: collect the begun dense search (its result is dropped) so
+        that the index accepts the next one."""
+        try:
+            if token is not None:
+                self._dense_chunks_end(token)
+        except Exception:
+            pass
+
     def _dense_chunks(self, query, k):
         return self._dense_chunks_end(self._dense_chunks_begin(query, k))
 
@@ -195,7 +204,11 @@ class SearchEngine:
             pending = self._dense_chunks_begin(query, top_k * 3 if retrieval_mode == "document" else top_k)
         sparse = []
         if "bm25" in self.vector_storage.indices_present:
-            sparse = self.search_bm25(query, top_k=top_k, retrieval_mode=retrieval_mode)   # beside the dense pass
+            try:
+                sparse = self.search_bm25(query, top_k=top_k, retrieval_mode=retrieval_mode)   # beside the dense pass
+            except Exception:
+                self._dense_abort(pending)
+                raise
         dense = self._dense_chunks_end(pending) if pending is not None else []
         fused = {}
         if retrieval_mode == "document":
@@ -285,6 +298,11 @@ class SearchEngine:
         tf_begun = self._tfidf_begin(query, top_k * 7)     # beside the dense pass, like the BM25 scoring below
         try:
             bm25_hits = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+        except Exception:
+            self._tfidf_abort(tf_begun)
+            self._dense_abort(pending[0] if pending else None)
+            raise
+        try:
             dense = {d["doc_id"]: d["score"] for d in self._search_faiss_end(pending)}
         except Exception:
             self._tfidf_abort(tf_begun)
@@ -328,6 +346,11 @@ class SearchEngine:
         tf_begun = self._tfidf_begin(query, top_k * 7)     # beside the dense pass, like the BM25 scoring below
         try:
             bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+        except Exception:
+            self._tfidf_abort(tf_begun)
+            self._dense_abort(pending[0] if pending else None)
+            raise
+        try:
             dense_ranking = self._search_faiss_end(pending)
             fused = self.reciprocal_rank_fusion(dense_ranking, bm25_ranking, k=60)
         except Exception:

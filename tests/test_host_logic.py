@@ -319,6 +319,42 @@ def test_mmr_and_cross_encoder_gpu(engine):
     _run_mmr_and_cross_encoder()
 
 
+@pytest.mark.gpu
+def test_tfidf_scoring_begun_early_gives_the_same_results_gpu(engine):
+    """search_rrf / search_multi_representation begin the TF-IDF scoring beside the dense pass
+    (rag_tfidf_query_begin) and collect it after the fusion: the same result lists as with the one-call
+    TF-IDF query, entry for entry, on a store large enough for the split to be taken (500 documents)."""
+    from rag_system_amd.search_engine import SearchEngine
+    mgr, store, em = _build_store(n_docs=500, seed=9, dim=96)
+    eng = SearchEngine(store, em)
+    begun = []
+    real_begin = eng._tfidf_begin
+
+    def counting_begin(query, k_bound):
+        tok = real_begin(query, k_bound)
+        begun.append(tok is not None)
+        return tok
+    queries = [" ".join(q) for q in zipf_queries(6, 400, seed=77)]
+    for method in ("search_rrf", "search_multi_representation"):
+        for q in queries:
+            eng._tfidf_begin = counting_begin
+            got = getattr(eng, method)(q, top_k=10)
+            eng._tfidf_begin = lambda *_a: None
+            exp = getattr(eng, method)(q, top_k=10)
+            _compare(got, exp)
+    assert begun and all(begun), begun
+    # a failing stage between the two halves leaves the scorer usable
+    eng._tfidf_begin = real_begin
+    real_bm25 = eng.search_bm25
+    eng.search_bm25 = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom"))
+    with pytest.raises(RuntimeError):
+        eng.search_rrf(queries[0], top_k=10)
+    eng.search_bm25 = real_bm25
+    again = eng.search_rrf(queries[0], top_k=10)
+    eng._tfidf_begin = lambda *_a: None
+    _compare(again, eng.search_rrf(queries[0], top_k=10))
+
+
 def test_query_row_normalisation_is_bit_identical_to_sklearn():
     """TfidfScorer._normalize_row restates sklearn.preprocessing.normalize + sort_indices for one row
     (what cosine_similarity does to the query, search_engine.py:285,331)."""
