@@ -35,6 +35,7 @@ struct Options {
     int64_t stream_bpc = 0;     // stream kernel blocks per CU (0 = auto)
     int64_t stream_nb = 0;      // stream kernel ring depth, 2 or 3 (0 = auto)
     int64_t mfma_pipe_sample = 0;  // -1: the pipelined tile kernel's filter flow samples with the list-mode tile kernel
+    int64_t sparse_rank_one = 0;    // -1: rag_tfidf_query_end ranks with the three rank kernels instead of the one-launch kernel
     int64_t wide_nb = 0;            // 3 / 4: ring depth of the wide kernel for up to two query tiles (0: by padding)
     int64_t prefilter_kp = 0;       // candidates per query of the bfloat16 prefilter (rag_flat_prefilter); 0: 64 (<= 8 queries, k <= 16) / 104
     int64_t prefilter_min_rows = 32768;  // smaller shards are searched directly

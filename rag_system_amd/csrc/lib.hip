@@ -109,6 +109,7 @@ int rag_set_option(const char* name, int64_t value) {
     else if (!std::strcmp(name, "stream_bpc")) o.stream_bpc = value;
     else if (!std::strcmp(name, "stream_nb")) o.stream_nb = value;
     else if (!std::strcmp(name, "stream_fuse")) o.stream_fuse = value;
+    else if (!std::strcmp(name, "sparse_rank_one")) o.sparse_rank_one = value;
     else if (!std::strcmp(name, "wide_nb")) o.wide_nb = value;
     else if (!std::strcmp(name, "prefilter_kp")) o.prefilter_kp = value;
     else if (!std::strcmp(name, "prefilter_min_rows")) o.prefilter_min_rows = value;

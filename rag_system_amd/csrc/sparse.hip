@@ -428,6 +428,127 @@ __global__ __launch_bounds__(RANK_MAXQ) void rank_final_kernel(const unsigned lo
     if (i < nq) rank[i] = pre[pos_of[i]] - 1ULL;
 }
 
+// The three kernels above in ONE launch, for up to RANK1_MAXQ queried rows (rag_tfidf_query_end: a hybrid query
+// asks for the ranks of its 30-60 fused candidates): every workgroup sorts the queried pairs itself (LDS, rank by
+// counting), bins its share of the rows, adds its bins to `hist` with agent-scope atomics and draws a ticket;
+// the workgroup that arrives last sums the prefix, writes ranks (and block 0 the gathered scores) -- to pinned
+// host memory -- and puts `hist` and the ticket back to zero for the next call (both start at zero: hipMemset
+// when they are allocated).
+constexpr int RANK1_MAXQ = 256;
+constexpr int RANK1_T = 256;
+constexpr int RANK1_RB = 8;  // rows per thread and chunk
+constexpr int RANK1_HREP = 16;  // copies of the histogram (workgroup b adds to copy b % 16): atomics on one line serialise
+struct Rank1Rows {
+    int r[RANK1_MAXQ];  // the queried rows travel as a kernel argument (1 KiB): 256-512 workgroups reading them from
+};                      // pinned host memory took ~10 us of the kernel's 23
+__global__ __launch_bounds__(RANK1_T) void rank_one_kernel(const double* __restrict__ score, long long n, int nq,
+                                                           const Rank1Rows qrow,
+                                                           unsigned long long* __restrict__ hist, int* __restrict__ ticket,
+                                                           unsigned long long* __restrict__ out_rank,
+                                                           double* __restrict__ out_score) {
+    __shared__ double uk[RANK1_MAXQ], ks[RANK1_MAXQ];
+    __shared__ long long ur[RANK1_MAXQ], rs[RANK1_MAXQ];
+    __shared__ int po[RANK1_MAXQ];
+    __shared__ unsigned int hh[RANK1_MAXQ + 1];
+    __shared__ unsigned long long pre[RANK1_MAXQ];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    if (tid < nq) {
+        const long long r = qrow.r[tid];
+        const double v = score[r];
+        ur[tid] = r;
+        uk[tid] = v;
+        if (out_score != nullptr && blockIdx.x == 0) out_score[tid] = v;
+    }
+    for (int i = tid; i <= nq; i += RANK1_T) hh[i] = 0;
+    __syncthreads();
+    if (tid < nq) {
+        const double k = uk[tid];
+        const long long r = ur[tid];
+        int pos = 0;
+        for (int j = 0; j < nq; ++j)  // a row queried twice: the earlier query sorts first
+            pos += (pair_ahead(uk[j], ur[j], k, r) || (uk[j] == k && ur[j] == r && j < tid)) ? 1 : 0;
+        po[tid] = pos;
+        ks[pos] = k;
+        rs[pos] = r;
+    }
+    __syncthreads();
+    // chunks of RANK1_RB * 256 consecutive rows; a thread's RANK1_RB searches run side by side (independent LDS
+    // reads per step: one search after the other was 28 us for 1M rows with one wave per SIMD)
+    const int lane = tid & 63;
+    const long long nchunks = (n + (long long)RANK1_T * RANK1_RB - 1) / ((long long)RANK1_T * RANK1_RB);
+    for (long long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const long long j0 = ch * RANK1_T * RANK1_RB + tid;
+        double v[RANK1_RB];
+        int lo[RANK1_RB], hi[RANK1_RB];
+#pragma unroll
+        for (int u = 0; u < RANK1_RB; ++u) {
+            const long long j = j0 + (long long)u * RANK1_T;
+            v[u] = j < n ? score[j] : 0.0;
+            lo[u] = 0;
+            hi[u] = j < n ? nq : 0;
+        }
+        for (int span = nq; span > 0; span >>= 1) {
+#pragma unroll
+            for (int u = 0; u < RANK1_RB; ++u) {
+                if (lo[u] < hi[u]) {  // first sorted position whose pair is NOT ahead of (v, j)
+                    const int mid = (lo[u] + hi[u]) >> 1;
+                    if (pair_ahead(ks[mid], rs[mid], v[u], j0 + (long long)u * RANK1_T)) lo[u] = mid + 1;
+                    else hi[u] = mid;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RANK1_RB; ++u) {
+            const int bin = j0 + (long long)u * RANK1_T < n ? lo[u] : -1;
+            const int b0 = __shfl(bin, 0, 64);  // most waves fall into one bin whole (the rows behind every queried pair)
+            if (__all(bin == b0)) {
+                if (lane == 0 && b0 >= 0) atomicAdd(&hh[b0], 64u);
+            } else if (bin >= 0) {
+                atomicAdd(&hh[bin], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // (the last bin -- rows behind every queried pair -- is never read)
+    if (tid < nq && hh[tid])
+        __hip_atomic_fetch_add(&hist[(blockIdx.x % RANK1_HREP) * RANK1_MAXQ + tid], (unsigned long long)hh[tid],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (int)gridDim.x - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < nq) {
+        unsigned long long a = 0;
+#pragma unroll
+        for (int r = 0; r < RANK1_HREP; ++r) {
+            a += __hip_atomic_load(&hist[r * RANK1_MAXQ + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&hist[r * RANK1_MAXQ + tid], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        pre[tid] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int p = 0; p < nq; ++p) {
+            run += pre[p];
+            pre[p] = run;
+        }
+    }
+    __syncthreads();
+    if (tid < nq) out_rank[tid] = pre[po[tid]] - 1ULL;
+}
+
 __global__ void gather_kernel(const double* __restrict__ score, int nq, const long long* __restrict__ qrow,
                               double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1063,6 +1184,7 @@ struct rag_csc {
     // rag_tfidf_query_begin / _end: the handle's own stream, the k of the begun query (0 = none begun)
     hipStream_t own_st = nullptr;
     int begun_k = 0;
+    unsigned long long* rk1_hist = nullptr;  // rank_one_kernel: [RANK1_HREP][RANK1_MAXQ] bins + ticket word behind them, zero between calls
     std::mutex mu;
 };
 
@@ -1382,6 +1504,7 @@ void rag_csc_free(rag_csc_t* h) {
     (void)hipFree(h->rk_pos);
     (void)hipFree(h->rk_hist);
     (void)hipFree(h->rk_gather);
+    (void)hipFree(h->rk1_hist);
     (void)hipFree(h->skip);
     (void)hipFree(h->wmax);
     (void)hipFree(h->bmax);
@@ -1613,6 +1736,25 @@ int rag_tfidf_query_end(rag_csc_t* h, int k, double* D, int64_t* I, int n_query,
     const long long* qrows = reinterpret_cast<const long long*>(h->pin + PIN_Q_ROWS);
     long long nb = (h->n_rows + 2047) / 2048;
     nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
+    if (want_ranks && n_query <= RANK1_MAXQ && options().sparse_rank_one >= 0) {
+        if (!h->rk1_hist) {
+            RAG_HIP(hipMalloc(&h->rk1_hist, (RANK1_HREP * RANK1_MAXQ + 8) * sizeof(unsigned long long)));
+            RAG_HIP(hipMemset(h->rk1_hist, 0, (RANK1_HREP * RANK1_MAXQ + 8) * sizeof(unsigned long long)));
+        }
+        const long long nb1 = std::max<long long>(1, std::min<long long>((h->n_rows + RANK1_T * RANK1_RB - 1) / (RANK1_T * RANK1_RB),
+                                                                         (long long)num_cus()));
+        Rank1Rows qr;
+        for (int i = 0; i < n_query; ++i) qr.r[i] = (int)rows[i];
+        rank_one_kernel<<<(unsigned)nb1, RANK1_T, 0, st>>>(h->score, (long long)h->n_rows, n_query, qr, h->rk1_hist,
+                                                          reinterpret_cast<int*>(h->rk1_hist + RANK1_HREP * RANK1_MAXQ),
+                                                          reinterpret_cast<unsigned long long*>(h->pin + PIN_Q_RANKS),
+                                                          want_scores ? reinterpret_cast<double*>(h->pin + PIN_Q_SCORES) : nullptr);
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipStreamSynchronize(st));
+        std::memcpy(ranks, h->pin + PIN_Q_RANKS, (size_t)n_query * sizeof(long long));
+        if (want_scores) std::memcpy(row_scores, h->pin + PIN_Q_SCORES, (size_t)n_query * sizeof(double));
+        return RAG_OK;
+    }
     rank_prep_kernel<<<1, RANK_MAXQ, 0, st>>>(h->score, n_query, qrows, h->rk_skey, h->rk_srow, h->rk_pos, h->rk_hist,
                                               reinterpret_cast<double*>(h->pin + PIN_Q_SCORES));
     if (want_ranks) {

@@ -314,7 +314,9 @@ def test_tfidf_query_in_two_halves_equals_one_call(engine):
     and the rank query delivered later -- bit-identical to rag_tfidf_query, also with a smaller k at the end,
     beside a BM25 scoring on another handle, with 1024 queried rows, after an abort; the handle refuses other
     calls while a query is begun."""
+    from rag_system_amd import _lib
     from rag_system_amd.bm25 import make_csc
+    lib = _lib.engine()
     rng = np.random.default_rng(67)
     n, nt = 300_000, 50
     df = rng.integers(200, 60_000, nt)
@@ -324,10 +326,11 @@ def test_tfidf_query_in_two_halves_equals_one_call(engine):
     h = make_csc(nt, n, indptr, rows, vals)
     other = make_csc(nt, n, indptr, rows, vals)
     n_split = 0
-    for trial in range(8):
+    for trial in range(12):
         t = rng.choice(nt, int(rng.integers(1, 8)), replace=False).astype(np.int32)
         w = rng.random(len(t))
-        q = rng.integers(0, n, int(rng.choice([1, 37, 1024]))).astype(np.int64)
+        q = rng.integers(0, n, int(rng.choice([1, 37, 256, 1024]))).astype(np.int64)
+        q[-1] = q[0]                                   # a row queried twice
         kb = int(rng.choice([10, 70, 200]))
         k = int(rng.integers(1, kb + 1))
         D0, I0, rk0, rs0 = h.tfidf_query(t, w, k, q)
@@ -341,7 +344,12 @@ def test_tfidf_query_in_two_halves_equals_one_call(engine):
         with pytest.raises(Exception):
             h.tfidf_query_begin(t, w, kb)
         other.tfidf_scores(t, w, want_scores=False, k=5)   # another handle works beside it (library stream)
-        D1, I1, rk1, rs1 = h.tfidf_query_end(k, q)
+        if trial % 3 == 2:       # the three rank kernels instead of the one-launch rank kernel (<= 256 rows)
+            _lib.check(lib.rag_set_option(b"sparse_rank_one", -1))
+        try:
+            D1, I1, rk1, rs1 = h.tfidf_query_end(k, q)
+        finally:
+            _lib.check(lib.rag_set_option(b"sparse_rank_one", 0))
         assert I1.tolist() == I0.tolist() and np.array_equal(_bits(D1), _bits(D0))
         assert rk1.tolist() == rk0.tolist() and np.array_equal(_bits(rs1), _bits(rs0))
     assert n_split >= 3
