@@ -9,6 +9,7 @@
 #include <vector>
 
 namespace rag {
+int flat_init_scratch() { return 0; }  // lib.hip's rag_init asks flat.hip for its scratch address; this harness has no flat.hip
 namespace mfma {
 int dispatch_bf16(const MfmaPlan& p, const Args& a) { return dispatch<true>(p, a); }
 int dispatch_f32(const MfmaPlan& p, const Args& a) { return dispatch<false>(p, a); }
