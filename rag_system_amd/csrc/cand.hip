@@ -208,7 +208,11 @@ __global__ __launch_bounds__(CAND_THREADS) void rrf_sort_kernel(const long long*
 // G (C x C cosine), simq (C).  One workgroup; selection order written to out_order.
 // STORED: candidate i is row rows[i] of a flat index' arena (fp32 or bfloat16 rows of `ld` elements) instead of
 // row i of `cand` -- the embeddings the index already holds, with no re-encoding and no upload.
-template <bool STORED>
+// LROWS (up to 64 candidates whose rows fit 96 KiB of LDS -- every call the search engine makes): the query and the
+// candidate rows are read from (pinned / HBM) memory ONCE into LDS and every later phase works there; the same
+// float operations in the same order as the path through `nrm` / `simq` in HBM, four memory round trips fewer.
+constexpr size_t MMR_LDS_BYTES = 96 << 10;
+template <bool STORED, bool LROWS>
 __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restrict__ cand, const float* __restrict__ q,
                                                            int C, int d, double lambda, int top_k,
                                                            const long long* __restrict__ byte_len, long long max_bytes,
@@ -231,16 +235,27 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
     __shared__ int s_pick;
     __shared__ long long s_bytes[MMR_MAX_C];  // read once: the inputs may sit in pinned host memory
     __shared__ float s_G[MMR_SMALL_C * MMR_SMALL_C];  // C <= 64: the Gram matrix never leaves the CU
+    extern __shared__ __align__(16) float mmr_dyn[];  // LROWS: [d] query, [C][d] rows
+    __shared__ float s_simq[MMR_SMALL_C];
     const bool small = C <= MMR_SMALL_C;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = CAND_THREADS / 64;
     for (int i = tid; i < C; i += CAND_THREADS) s_bytes[i] = byte_len[i];
+    if (LROWS) {
+        for (int c = tid; c < d; c += CAND_THREADS) mmr_dyn[c] = q[c];
+        for (size_t e = tid; e < (size_t)C * d; e += CAND_THREADS) mmr_dyn[d + e] = cval((int)(e / d), (int)(e % d));
+        __syncthreads();
+        q = mmr_dyn;
+        nrm = mmr_dyn + d;
+        simq = s_simq;
+    }
+    auto rval = [&](int i, int c) -> float { return LROWS ? nrm[(size_t)i * d + c] : cval(i, c); };
 
     // row norms (one wave per row), query norm
     for (int i = wid; i <= C; i += NW) {
         float ss = 0.f;
         for (int c = lane; c < d; c += 64) {
-            const float x = i < C ? cval(i, c) : q[c];
+            const float x = i < C ? rval(i, c) : q[c];
             ss = fmaf(x, x, ss);
         }
         for (int dist = 32; dist >= 1; dist >>= 1) ss += __shfl_xor(ss, dist);
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (size_t e = tid; e < (size_t)C * d; e += CAND_THREADS) nrm[e] = cval((int)(e / d), (int)(e % d)) / s_inv[e / d];
+    for (size_t e = tid; e < (size_t)C * d; e += CAND_THREADS) nrm[e] = rval((int)(e / d), (int)(e % d)) / s_inv[e / d];
     __syncthreads();
     // cosine to the query and the Gram matrix (one wave per dot product)
     for (int i = wid; i < C; i += NW) {
@@ -552,20 +567,29 @@ static int mmr_call(int C, int d, const float* cand, const long long* rows, cons
     char* kin = zero_copy ? hin : din;
     char* kout = zero_copy ? hout : dout;
     if (!zero_copy) RAG_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, st));
-    if (stored)
-        mmr_kernel<true><<<1, CAND_THREADS, 0, st>>>(nullptr, reinterpret_cast<float*>(kin + cand_b), C, d, lambda, top_k,
-                                                    reinterpret_cast<long long*>(kin + cand_b + q_b), (long long)max_bytes,
-                                                    reinterpret_cast<float*>(dnrm), reinterpret_cast<float*>(dG),
-                                                    reinterpret_cast<float*>(dsimq), reinterpret_cast<int*>(kout + 8),
-                                                    reinterpret_cast<int*>(kout), reinterpret_cast<long long*>(kin), arena,
-                                                    ld, bf16);
-    else
-        mmr_kernel<false><<<1, CAND_THREADS, 0, st>>>(reinterpret_cast<float*>(kin), reinterpret_cast<float*>(kin + cand_b), C,
-                                                     d, lambda, top_k, reinterpret_cast<long long*>(kin + cand_b + q_b),
-                                                     (long long)max_bytes, reinterpret_cast<float*>(dnrm),
-                                                     reinterpret_cast<float*>(dG), reinterpret_cast<float*>(dsimq),
-                                                     reinterpret_cast<int*>(kout + 8), reinterpret_cast<int*>(kout), nullptr,
-                                                     nullptr, 0, 0);
+    const size_t lds_b = ((size_t)C * d + d) * sizeof(float);
+    const bool lrows = C <= MMR_SMALL_C && lds_b <= MMR_LDS_BYTES;
+    auto launch = [&](auto fn, size_t smem) {
+        if (smem > 0) {
+            static bool attr_done[4] = {false, false, false, false};  // under ws.mu
+            const int slot = (stored ? 2 : 0) + 1;
+            if (!attr_done[slot]) {
+                RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)MMR_LDS_BYTES));
+                attr_done[slot] = true;
+            }
+        }
+        fn<<<1, CAND_THREADS, smem, st>>>(stored ? nullptr : reinterpret_cast<float*>(kin), reinterpret_cast<float*>(kin + cand_b), C, d,
+                                          lambda, top_k, reinterpret_cast<long long*>(kin + cand_b + q_b), (long long)max_bytes,
+                                          reinterpret_cast<float*>(dnrm), reinterpret_cast<float*>(dG),
+                                          reinterpret_cast<float*>(dsimq), reinterpret_cast<int*>(kout + 8),
+                                          reinterpret_cast<int*>(kout), stored ? reinterpret_cast<long long*>(kin) : nullptr,
+                                          stored ? arena : nullptr, stored ? ld : 0, stored ? bf16 : 0);
+        return RAG_OK;
+    };
+    if (stored) rc = lrows ? launch(mmr_kernel<true, true>, lds_b) : launch(mmr_kernel<true, false>, 0);
+    else rc = lrows ? launch(mmr_kernel<false, true>, lds_b) : launch(mmr_kernel<false, false>, 0);
+    if (rc) return rc;
     RAG_HIP(hipGetLastError());
     if (!zero_copy) RAG_HIP(hipMemcpyAsync(hout, dout, out_b, hipMemcpyDeviceToHost, st));
     RAG_HIP(hipStreamSynchronize(st));
