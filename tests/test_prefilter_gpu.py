@@ -257,3 +257,38 @@ def test_vector_storage_dense_prefilter_same_hits(engine):
     for a, b in zip(plain + plain_b + [plain[0]], got + got_b + [got_be]):
         assert [h["chunk"] for h in a] == [h["chunk"] for h in b]
         assert np.allclose([h["score"] for h in a], [h["score"] for h in b], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_prefilter_device_entry_point_with_id_base(engine, metric):
+    """rag_flat_search_dev on a caller's stream with a non-zero id_base (one shard of a row-sharded index): the
+    prefiltered search stays asynchronous -- proof and redo run on the device -- and returns global ids, for
+    queries the bound proves and for queries it cannot (a cluster of near-duplicates)."""
+    import torch
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(123 + metric)
+    d, base = 96, 5_000_000_000
+    dup = _rand_unit(rng, 1, d)
+    cluster = (dup + 1e-3 * rng.standard_normal((15_000, d)).astype(np.float32) / np.sqrt(d)).astype(np.float32)
+    X = np.concatenate([_rand_unit(rng, 45_000, d), cluster])
+    X = X[rng.permutation(len(X))]
+    idx = faiss.IndexFlat(d, metric)
+    idx.add(X)
+    idx.set_prefilter(True)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    for nq, k in [(1, 10), (6, 5), (50, 10), (260, 8)]:
+        Q = _rand_unit(rng, nq, d)
+        Q[nq // 2] = dup[0]                      # this one cannot be proved
+        with torch.cuda.stream(stream):
+            q_dev = torch.from_numpy(Q).to(dev)
+            D_dev = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            I_dev = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        idx._b.search_dev(nq, q_dev.data_ptr(), k, D_dev.data_ptr(), I_dev.data_ptr(), base, stream.cuda_stream)
+        stream.synchronize()
+        assert idx._b.last_kernel().startswith("prefilter")
+        assert 1 <= idx._b.prefilter_redone() < max(nq, 2)
+        D, I = D_dev.cpu().numpy(), I_dev.cpu().numpy()
+        assert (I >= base).all()
+        _, Ir, D64 = od.flat_search(X, Q, k, metric)
+        od.check_topk(D, I - base, D64, Ir, RTOL, ATOL if metric == 0 else 4e-6, _scorer(X, Q, metric))
