@@ -1192,7 +1192,9 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     // 8.9 / 9.0 / 9.4 / 16.2 ms on the tile kernel against 3.65-4.5 ms per pass).
     // fp32 rows only: bfloat16 passes are bound by re-reading the rows, and the tile kernel needs
     // one pass (10M x 768 bf16, 65 / 128 queries: 4.2 / 4.4 ms against 5.2 / 5.8 ms in chunks).
-    if (!bf && nq > 64 && nq <= 192 && k <= 128 && n >= opt.mfma_filter_min_rows && opt.mfma_filter_k <= 1 &&
+    // (not with the bfloat16 prefilter on: its copy takes the whole batch in one pass of the bf16 tile kernel)
+    const bool prefiltered = h->shadow != nullptr && !bf && n >= opt.prefilter_min_rows && 4 * k <= 104 && opt.prefilter_kp == 0;
+    if (!bf && !prefiltered && nq > 64 && nq <= 192 && k <= 128 && n >= opt.mfma_filter_min_rows && opt.mfma_filter_k <= 1 &&
         (opt.wide_max_nq == 0 || opt.wide_max_nq >= 64) && opt.mfma_min_nq <= 64) {
         WidePlan probe;
         if (wide_plan(n, 64, dch, bf, 1, 1024, 32, &probe)) {
