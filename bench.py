@@ -112,7 +112,7 @@ def cpu_baseline(args, Q):
     return out
 
 
-def kernel_name(nq, k, n_local, bf):
+def kernel_name(nq, k, n_local, bf, d=0):
     """Which kernel makes the timed pass (the engine's dispatch, csrc/flat.hip search_device; the
     rocprofv3 summaries under profiles/ show the same names)."""
     if k > 128:
@@ -122,6 +122,8 @@ def kernel_name(nq, k, n_local, bf):
     if nq <= 192 and n_local >= (1 << 19) and (nq <= 64 or not bf):
         return "flat_wide_kernel (sample + filter passes%s)" % (
             "" if nq <= 64 else ", %d query chunks" % ((nq + 63) // 64))
+    if bf and nq > 64 and d % 64 == 0 and k >= (16 if nq <= 128 else 33):
+        return "flat_pipe_kernel (filter flow: sample pass + filter pass)"
     return "flat_mfma_kernel"
 
 
@@ -141,7 +143,7 @@ def roofline(nq, k, n_local, d, bf, n_launch, scan_ms, bytes_per_launch, steps):
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach / mfma_peak,
                 "traffic": None}
-    roof.update({"kernel": kernel_name(nq, k, n_local, bf), "avg_launch_ms": avg_ms, "launches": n_launch,
+    roof.update({"kernel": kernel_name(nq, k, n_local, bf, d), "avg_launch_ms": avg_ms, "launches": n_launch,
                  "algorithmic_bytes_per_launch": bytes_per_launch})
     return roof
 
