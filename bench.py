@@ -289,15 +289,63 @@ class Runner:
         return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_gpus, argv, child_cmd=None):
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (WORLD_SIZE unset, N > 1): this
+    process becomes a plain launcher.  It has not touched the GPU (no torch import, no engine call, and
+    it never re-execs itself): it starts `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a CHILD process, passes the children's stderr through, relays rank 0's one JSON
+    line to its own stdout and returns the child's exit code.  `child_cmd` (or the environment variable
+    RAG_BENCH_LAUNCH_CMD, a JSON list) replaces the launcher command; tests/test_bench_launch_cpu.py
+    uses it to run this branch without GPUs."""
+    import subprocess
+    if child_cmd is None and os.environ.get("RAG_BENCH_LAUNCH_CMD"):
+        child_cmd = json.loads(os.environ["RAG_BENCH_LAUNCH_CMD"])
+    if child_cmd is None:
+        child_cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                     "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+                     "--master-port", str(free_port()), os.path.abspath(__file__)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    log("launching %d ranks: %s" % (n_gpus, " ".join(child_cmd + list(argv))))
+    proc = subprocess.Popen(child_cmd + list(argv), stdout=subprocess.PIPE, env=env, text=True)
+    line, other = None, []
+    for raw in proc.stdout:              # stderr is inherited: progress lines stream through
+        s = raw.strip()
+        if s.startswith("{") and '"metric"' in s:
+            try:
+                json.loads(s)
+                line = s
+                continue
+            except ValueError:
+                pass
+        other.append(raw)
+    rc = proc.wait()
+    for raw in other:                    # anything else a rank printed goes to stderr, never to stdout
+        sys.stderr.write(raw)
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py launcher: the ranks exited 0 without printing a result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            sys.exit(self_launch(args.gpus, sys.argv[1:]))
         args.gpus = world
 
     import numpy as np
