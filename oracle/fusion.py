@@ -1,6 +1,8 @@
 """CPU restatement of the candidate-set stages -- TEST INFRASTRUCTURE ONLY (oracle/__init__.py).
 
-Restated from the reference source (it has no tests or fixtures: PARITY UNPINNED):
+Restated from the reference source and PINNED (round 3) against the outputs of the reference's own
+rag_system/search_engine.py: tests/golden/strategy_golden.json, written in the build container by
+tests/golden/make_strategy_golden.py, replayed by tests/test_strategy_golden.py (exact equality):
   reciprocal_rank_fusion   search_engine.py:352-359
   mmr_selection            search_engine.py:396-468 (numeric part; embeddings are inputs)
   detect_knee              search_engine.py:37-48
