@@ -118,6 +118,17 @@ int rag_postings_build(int64_t n_docs, const int64_t* doc_indptr, int64_t n_toke
     *nnz_out = 0;
     indptr[0] = 0;
     if (n_tokens == 0) return RAG_OK;
+    if (n_words == 0) return fail(RAG_ERR_INVALID_ARG, "rag_postings_build: a word id outside [0, n_words) (n_words = 0)");
+    // host targets / sources of asynchronous copies, declared before `drain` so that every return path --
+    // the error returns included -- waits for the stream before they go out of scope
+    std::vector<long long> first((size_t)n_words);
+    std::vector<int> w2t((size_t)n_words, -1);
+    int bad = 0;
+    unsigned long long nruns = 0;
+    struct Drain {
+        hipStream_t st;
+        ~Drain() { (void)hipStreamSynchronize(st); }
+    } drain{st};
 
     DevBuf d_words, d_indptr, d_first, d_bad, d_w2t, d_keys, d_keys2, d_ukeys, d_counts, d_nruns, d_tmp, d_rows, d_tf, d_pind;
     if ((rc = d_words.alloc((size_t)n_tokens * 4)) || (rc = d_indptr.alloc((size_t)(n_docs + 1) * 8)) ||
@@ -130,8 +141,6 @@ int rag_postings_build(int64_t n_docs, const int64_t* doc_indptr, int64_t n_toke
     fill_i64_kernel<<<(unsigned)((n_words + 255) / 256), 256, 0, st>>>(d_first.as<long long>(), n_words, NO_POS);
     first_pos_kernel<<<nb, 256, 0, st>>>(d_words.as<int>(), n_tokens, n_words, d_first.as<long long>(), d_bad.as<int>());
     RAG_HIP(hipGetLastError());
-    std::vector<long long> first((size_t)n_words);
-    int bad = 0;
     RAG_HIP(hipMemcpyAsync(first.data(), d_first.p, (size_t)n_words * 8, hipMemcpyDeviceToHost, st));
     RAG_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
     RAG_HIP(hipStreamSynchronize(st));
@@ -144,7 +153,6 @@ int rag_postings_build(int64_t n_docs, const int64_t* doc_indptr, int64_t n_toke
         if (first[(size_t)w] != NO_POS) seen.push_back((int)w);
     std::sort(seen.begin(), seen.end(), [&](int a, int b) { return first[(size_t)a] < first[(size_t)b]; });
     const long long n_terms = (long long)seen.size();
-    std::vector<int> w2t((size_t)n_words, -1);
     for (long long t = 0; t < n_terms; ++t) {
         term_word[t] = seen[(size_t)t];
         w2t[(size_t)seen[(size_t)t]] = (int)t;
@@ -175,7 +183,6 @@ int rag_postings_build(int64_t n_docs, const int64_t* doc_indptr, int64_t n_toke
     RAG_HIP(rocprim::run_length_encode(d_tmp2.p, tmp2, d_keys2.as<unsigned long long>(), (unsigned int)n_tokens,
                                        d_keys.as<unsigned long long>(), d_counts.as<unsigned int>(),
                                        d_nruns.as<unsigned long long>(), st));
-    unsigned long long nruns = 0;
     RAG_HIP(hipMemcpyAsync(&nruns, d_nruns.p, 8, hipMemcpyDeviceToHost, st));
     RAG_HIP(hipStreamSynchronize(st));
     const long long nnz = (long long)nruns;

@@ -620,16 +620,28 @@ int rag_flat_mmr(rag_flat_t* h, int C, const int64_t* rows, const float* q, doub
     if (!rows || !q || !byte_len || !out_order) return fail(RAG_ERR_INVALID_ARG, "NULL buffer");
     if (C > MMR_MAX_C)
         return fail(RAG_ERR_UNSUPPORTED, "%d candidates exceed the candidate-set limit %d", C, MMR_MAX_C);
-    const void* arena = nullptr;
-    int ld = 0, d = 0, bf16 = 0;
-    int64_t n = 0;
-    int rc = flat_view(h, &arena, &ld, &d, &bf16, &n);   // flushes staged rows; rows are in HBM afterwards
-    if (rc) return rc;
-    for (int i = 0; i < C; ++i)
-        if (rows[i] < 0 || rows[i] >= n)
-            return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)rows[i], (long long)n);
-    return mmr_call(C, d, nullptr, reinterpret_cast<const long long*>(rows), arena, ld, bf16, q, lambda, top_k, byte_len,
-                    max_bytes, out_order, out_n);
+    // the whole selection runs under the index' mutex (rag::flat_with_view): the kernel gathers the candidate
+    // rows from the arena, which a concurrent rag_flat_add could otherwise reallocate between the view and the
+    // launch
+    struct Ctx {
+        int C;
+        const int64_t* rows;
+        const float* q;
+        double lambda;
+        int top_k;
+        const int64_t* byte_len;
+        int64_t max_bytes;
+        int32_t* out_order;
+        int* out_n;
+    } ctx{C, rows, q, lambda, top_k, byte_len, max_bytes, out_order, out_n};
+    return flat_with_view(h, [](const FlatView& v, void* p) -> int {
+        const Ctx& c = *static_cast<const Ctx*>(p);
+        for (int i = 0; i < c.C; ++i)
+            if (c.rows[i] < 0 || c.rows[i] >= v.n_rows)
+                return fail(RAG_ERR_INVALID_ARG, "row %lld outside [0,%lld)", (long long)c.rows[i], (long long)v.n_rows);
+        return mmr_call(c.C, v.d, nullptr, reinterpret_cast<const long long*>(c.rows), v.arena, v.ld, v.bf16, c.q,
+                        c.lambda, c.top_k, c.byte_len, c.max_bytes, c.out_order, c.out_n);
+    }, &ctx);
 }
 
 }  // extern "C"

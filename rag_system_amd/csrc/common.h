@@ -48,8 +48,15 @@ struct Options {
 };
 Options& options();
 // flat.hip: read-only view of a flat index' arena after flushing its staged rows (rows of `ld` elements, fp32 or
-// bfloat16); valid until the next add / reset on the handle
-int flat_view(rag_flat_t* h, const void** arena, int* ld, int* d, int* bf16, int64_t* n_rows);
+// bfloat16).  `use` runs WITH THE HANDLE'S MUTEX HELD and must have ENQUEUED every kernel that reads the arena
+// before it returns: a concurrent rag_flat_add may then grow the arena, but its hipFree of the old one waits for
+// the kernels already enqueued (the reference's UI adds documents beside its query thread, UI_manager.py:753,883).
+struct FlatView {
+    const void* arena;
+    int ld, d, bf16;
+    int64_t n_rows;
+};
+int flat_with_view(rag_flat_t* h, int (*use)(const FlatView&, void*), void* ctx);
 int flat_init_scratch();  // flat.hip: address of the no-allocation entry point's scratch on the current device
 
 }  // namespace rag

@@ -677,38 +677,27 @@ __global__ __launch_bounds__(PF_THREADS) void prefilter_rescore_kernel(
     __shared__ float s_e[PF_MAX_KP];               // exact score, same sense
     __shared__ int s_id[PF_MAX_KP];
     __shared__ unsigned char s_need[PF_MAX_KP];
-    __shared__ double s_red[2][PF_THREADS / 64];
+    __shared__ double s_red[1][PF_THREADS / 64];
     __shared__ double s_L, s_B;
     __shared__ float s_Ek;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* qrow = Q + (long long)q * d;
-    double qq = 0.0, qqb = 0.0;
+    double qq = 0.0;
     for (int c = tid; c < ld; c += PF_THREADS) {
         const float v = c < d ? qrow[c] : 0.0f;
         s_q[c] = v;
-        const float vb = __uint_as_float((unsigned int)bf16_rne(v) << 16);
         qq += (double)v * (double)v;
-        qqb += (double)vb * (double)vb;
     }
-    for (int dist = 32; dist >= 1; dist >>= 1) {
-        qq += __shfl_xor(qq, dist);
-        qqb += __shfl_xor(qqb, dist);
-    }
-    if (lane == 0) {
-        s_red[0][wid] = qq;
-        s_red[1][wid] = qqb;
-    }
+    for (int dist = 32; dist >= 1; dist >>= 1) qq += __shfl_xor(qq, dist);
+    if (lane == 0) s_red[0][wid] = qq;
     if (tid == 0) {
         s_L = __builtin_nan("");
         s_B = __builtin_inf();
         s_Ek = __builtin_nanf("");
     }
     __syncthreads();
-    qq = qqb = 0.0;
-    for (int w = 0; w < PF_THREADS / 64; ++w) {
-        qq += s_red[0][w];
-        qqb += s_red[1][w];
-    }
+    qq = 0.0;
+    for (int w = 0; w < PF_THREADS / 64; ++w) qq += s_red[0][w];
     const double mx2 = (double)__uint_as_float(*max_bits);
     double eps = eps_rel * sqrt(mx2 * qq);
     if (METRIC == RAG_METRIC_L2) eps = 2.0 * eps + slack * (mx2 + qq);  // + the fp32 roundings of both norms and of the key
@@ -720,8 +709,10 @@ __global__ __launch_bounds__(PF_THREADS) void prefilter_rescore_kernel(
         const long long id = pI[(long long)q * kp + tid];
         valid = id >= 0 && id < n;
         const double v = (double)pD[(long long)q * kp + tid];
-        // the shadow's distance holds ||bf16(q)||^2 where the exact one holds ||q||^2: the same shift for every row
-        if (valid) a = METRIC == RAG_METRIC_IP ? v : -(v - (qqb - qq));
+        // L2: the shadow's distance is ||x||^2 + ||q||^2 - 2<bf16(x), bf16(q)> with BOTH norms taken from the fp32
+        // operands (sync_shadow copies the fp32 rows' norms, prepare_l2_norms squares the fp32 query), so only
+        // the cross term carries the rounding and eps (twice the inner-product bound) covers it; no shift
+        if (valid) a = METRIC == RAG_METRIC_IP ? v : -v;
         s_a[tid] = a;
         s_id[tid] = valid ? (int)id : -1;
     }
@@ -1690,17 +1681,13 @@ int search_device_noalloc(rag_flat* h, int64_t nq, const float* q_dev, int k, fl
 }  // namespace
 
 namespace rag {
-int flat_view(rag_flat_t* h, const void** arena, int* ld, int* d, int* bf16, int64_t* n_rows) {
+int flat_with_view(rag_flat_t* h, int (*use)(const FlatView&, void*), void* ctx) {
     std::lock_guard<std::mutex> lk(h->mu);
     const int rc = flush_staged(h);
     if (rc) return rc;
     RAG_HIP(hipStreamSynchronize(lib_stream()));
-    *arena = h->x;
-    *ld = h->ld;
-    *d = h->d;
-    *bf16 = h->dtype == RAG_DTYPE_BF16 ? 1 : 0;
-    *n_rows = h->ndev;
-    return RAG_OK;
+    const FlatView v{h->x, h->ld, h->d, h->dtype == RAG_DTYPE_BF16 ? 1 : 0, h->ndev};
+    return use(v, ctx);
 }
 // Called by rag_init() with the selected device current, once per process (one process per GPU).
 int flat_init_scratch() {
@@ -1735,6 +1722,12 @@ int rag_flat_create(int d, int metric, int storage_dtype, rag_flat_t** out) {
     h->ld = storage_dtype == RAG_DTYPE_BF16 ? ((d + 7) & ~7) : ((d + 3) & ~3);
     h->metric = metric;
     h->dtype = storage_dtype;
+    // the ordering event exists from the start, so that order_after_previous never creates anything
+    // (rag_flat_search_dev_noalloc calls it too)
+    if (hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return fail(RAG_ERR_HIP, "hipEventCreateWithFlags failed");
+    }
     *out = h;
     return RAG_OK;
 }
@@ -1949,6 +1942,10 @@ int rag_flat_search_dev_noalloc(rag_flat_t* h, int64_t nq, const float* q_dev, i
     if (g_scratch_ptr == nullptr || dev != g_scratch_dev)
         return fail(RAG_ERR_NOT_INIT, "rag_flat_search_dev_noalloc: no scratch address for device %d (rag_init ran on %d)",
                     dev, g_scratch_dev);
+    // ordered behind the handle's previous search when that ran on another stream (it may still be writing the
+    // L2 row norms this one reads): an event record + wait, nothing is created or allocated
+    const int rc = order_after_previous(h, (hipStream_t)stream);
+    if (rc) return rc;
     return search_device_noalloc(h, nq, q_dev, k, D_dev, reinterpret_cast<long long*>(I_dev), id_base,
                                  (hipStream_t)stream, g_scratch_ptr);
 }

@@ -11,8 +11,10 @@ constructing an index without the library or without a GPU raises EngineUnavaila
 `set_backend_factory` exists so that host-logic tests can inject the CPU oracle; nothing in
 the product calls it.
 """
+import contextlib
 import ctypes as C
 import struct
+import threading
 
 import numpy as np
 
@@ -141,6 +143,13 @@ class IndexFlat:
         self.storage = storage
         self._b = (_backend_factory(self.d, self.metric_type) if storage == "f32"
                    else _backend_factory(self.d, self.metric_type, storage))
+        # A handle takes ONE begun search at a time and refuses every other search until it is ended
+        # (rag_flat_search_begin).  The reference's UI starts one thread per query (UI_manager.py:883), so the
+        # searches of different threads are serialised here: search_begin holds the lock until search_end, a
+        # blocking search waits for it.  (A thread that begins twice without ending is a caller's bug: it is
+        # not made to wait for itself, the library's refusal reaches it.)
+        self._search_lock = threading.Lock()
+        self._begun_by = None
 
     @property
     def ntotal(self):
@@ -162,7 +171,16 @@ class IndexFlat:
             raise ValueError("k must be positive")
         if x.shape[0] == 0:
             return np.empty((0, k), dtype=np.float32), np.empty((0, k), dtype=np.int64)
-        return self._b.search(x, k)
+        with self._serialised():
+            return self._b.search(x, k)
+
+    @contextlib.contextmanager
+    def _serialised(self):
+        if self._begun_by == threading.get_ident():
+            yield       # this thread's own begun search is pending: let the library say so
+            return
+        with self._search_lock:
+            yield
 
     def search_begin(self, x, k):
         """search() in two halves (not in faiss): returns a token for search_end().  The dense pass runs
@@ -177,11 +195,27 @@ class IndexFlat:
         small = x.shape[0] * (self.d * 4 + 12 * k) + 64 <= (4 << 20)   # fits the pinned staging buffer
         if x.shape[0] == 0 or not small or not hasattr(self._b, "search_begin"):
             return ("done", self.search(x, k))        # nothing to overlap (or a backend without the split)
-        return ("pending", self._b.search_begin(x, k))
+        if self._begun_by == threading.get_ident():
+            return ("pending-unlocked", self._b.search_begin(x, k))    # refused by the library with its message
+        self._search_lock.acquire()
+        try:
+            tok = self._b.search_begin(x, k)
+        except BaseException:
+            self._search_lock.release()
+            raise
+        self._begun_by = threading.get_ident()
+        return ("pending", tok)
 
     def search_end(self, token):
         kind, val = token
-        return val if kind == "done" else self._b.search_end(val)
+        if kind == "done":
+            return val
+        try:
+            return self._b.search_end(val)
+        finally:
+            if kind == "pending":
+                self._begun_by = None
+                self._search_lock.release()
 
     def reset(self):
         self._b.reset()

@@ -13,7 +13,9 @@ here M is re-normalised ONCE at upload (sklearn.preprocessing.normalize, the sam
 cosine_similarity calls), stored term-major in HBM, and each query runs rag_tfidf_scores
 (csrc/sparse.hip), which adds w_t * M[doc, t] term by term in scipy's order.
 """
+import contextlib
 import math
+import threading
 
 import numpy as np
 
@@ -30,6 +32,18 @@ class TfidfScorer:
         csc.sort_indices()
         self._csc = _bm25.make_csc(self.n_terms, self.n_docs, csc.indptr.astype(np.int64),
                                    csc.indices.astype(np.int32), csc.data.astype(np.float64))
+        # one begun query per handle (rag_tfidf_query_begin): queries of different threads (the reference's UI
+        # runs one thread per query, UI_manager.py:883) wait for each other here instead of being refused
+        self._lock = threading.Lock()
+        self._begun_by = None
+
+    @contextlib.contextmanager
+    def _serialised(self):
+        if self._begun_by == threading.get_ident():
+            yield
+            return
+        with self._lock:
+            yield
 
     @staticmethod
     def _normalize_row(indices, data):
@@ -59,19 +73,22 @@ class TfidfScorer:
     def scores_from_row(self, indices, data):
         """Scores for an already vectorised query row (the output of vectorizer.transform)."""
         t, w = self._normalize_row(indices, data)
-        s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
+        with self._serialised():
+            s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
         return s
 
     def top_k_from_row(self, indices, data, k):
         """top_k() for an already vectorised query row (k <= MAX_FUSED_K)."""
         t, w = self._normalize_row(indices, data)
-        _, D, I = self._csc.tfidf_scores(t, w, want_scores=False, k=min(int(k), self.n_docs))
+        with self._serialised():
+            _, D, I = self._csc.tfidf_scores(t, w, want_scores=False, k=min(int(k), self.n_docs))
         return I, D
 
     def scores(self, query):
         """cosine_similarity(vectorizer.transform([query]), matrix)[0] as float64 (n_docs,)."""
         t, w = self._query(query)
-        s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
+        with self._serialised():
+            s, _, _ = self._csc.tfidf_scores(t, w, want_scores=True, k=0)
         return s
 
     def top_k(self, query, k):
@@ -82,7 +99,8 @@ class TfidfScorer:
             s = self.scores(query)
             ids = np.array(sorted(range(len(s)), key=lambda i: s[i], reverse=True)[:k], dtype=np.int64)
             return ids, s[ids]
-        _, D, I = self._csc.tfidf_scores(t, w, want_scores=False, k=k)
+        with self._serialised():
+            _, D, I = self._csc.tfidf_scores(t, w, want_scores=False, k=k)
         return I, D
 
     def ranks(self, doc_indices):
@@ -98,7 +116,8 @@ class TfidfScorer:
     def ranks_from_row(self, indices, data, k, doc_indices):
         """(top_idx, top_scores, ranks): top_k_from_row(k) + ranks(doc_indices) in one engine call."""
         t, w = self._normalize_row(indices, data)
-        D, I, ranks, _ = self._csc.tfidf_query(t, w, min(int(k), self.n_docs), doc_indices, want_scores=False)
+        with self._serialised():
+            D, I, ranks, _ = self._csc.tfidf_query(t, w, min(int(k), self.n_docs), doc_indices, want_scores=False)
         return I, D, ranks
 
     def query(self, query, k, doc_indices):
@@ -108,11 +127,18 @@ class TfidfScorer:
         fused = getattr(self._csc, "tfidf_query", None)
         if (fused is None or k > _bm25.BM25Okapi.MAX_FUSED_K or not len(doc_indices)
                 or len(doc_indices) > getattr(self._csc, "MAX_QUERY_ROWS", 0)):
-            I, D = self.top_k(query, k)
-            has = len(doc_indices) > 0
-            return I, D, (self.ranks(doc_indices) if has else []), (self.gather(doc_indices) if has else [])
+            # three engine calls that belong together (ranks / gather read the scores of the top_k call)
+            with self._serialised():
+                prev, self._begun_by = self._begun_by, threading.get_ident()
+                try:
+                    I, D = self.top_k(query, k)
+                    has = len(doc_indices) > 0
+                    return I, D, (self.ranks(doc_indices) if has else []), (self.gather(doc_indices) if has else [])
+                finally:
+                    self._begun_by = prev
         t, w = self._query(query)
-        D, I, ranks, sc = fused(t, w, k, doc_indices)
+        with self._serialised():
+            D, I, ranks, sc = fused(t, w, k, doc_indices)
         return I, D, ranks, sc
 
     # ---- the same in two halves (rag_tfidf_query_begin / _end): scoring needs only the query ------------
@@ -120,9 +146,26 @@ class TfidfScorer:
     def _begin_row(self, t, w, k_bound):
         k_bound = min(int(k_bound), self.n_docs)
         begin = getattr(self._csc, "tfidf_query_begin", None)
-        if begin is None or k_bound < 1 or k_bound > _bm25.BM25Okapi.MAX_FUSED_K or not begin(t, w, k_bound):
+        if begin is None or k_bound < 1 or k_bound > _bm25.BM25Okapi.MAX_FUSED_K:
             return None
+        if self._begun_by == threading.get_ident():
+            return None                 # this thread already has a begun query: the caller uses query()
+        self._lock.acquire()            # held until query_end / query_abort
+        try:
+            ok = begin(t, w, k_bound)
+        except BaseException:
+            self._lock.release()
+            raise
+        if not ok:
+            self._lock.release()
+            return None
+        self._begun_by = threading.get_ident()
         return k_bound
+
+    def _release_begun(self):
+        if self._begun_by is not None:
+            self._begun_by = None
+            self._lock.release()
 
     def query_begin(self, query, k_bound):
         """Enqueue the scoring of `query` and the selection of its k_bound best documents; returns a token for
@@ -136,15 +179,21 @@ class TfidfScorer:
         query_begin, len(doc_indices) <= MAX_QUERY_ROWS."""
         kb = token[1]
         k = min(int(k), self.n_docs, kb)
-        if len(doc_indices) > getattr(self._csc, "MAX_QUERY_ROWS", 0):   # more rows than one rank query takes
-            D, I, _, _ = self._csc.tfidf_query_end(k, [])
-            return I, D, self.ranks(doc_indices), self.gather(doc_indices)
-        D, I, ranks, sc = self._csc.tfidf_query_end(k, doc_indices)
-        return I, D, ranks, sc
+        try:
+            if len(doc_indices) > getattr(self._csc, "MAX_QUERY_ROWS", 0):   # more rows than one rank query takes
+                D, I, _, _ = self._csc.tfidf_query_end(k, [])
+                return I, D, self.ranks(doc_indices), self.gather(doc_indices)
+            D, I, ranks, sc = self._csc.tfidf_query_end(k, doc_indices)
+            return I, D, ranks, sc
+        finally:
+            self._release_begun()
 
     def query_abort(self, token):
         """Give up a begun query (the handle accepts other calls again)."""
-        self._csc.tfidf_query_abort()
+        try:
+            self._csc.tfidf_query_abort()
+        finally:
+            self._release_begun()
 
     def ranks_from_row_begin(self, indices, data, k_bound):
         t, w = self._normalize_row(indices, data)
@@ -152,5 +201,9 @@ class TfidfScorer:
         return None if kb is None else ("tfidf-begun", kb)
 
     def ranks_from_row_end(self, token, k, doc_indices):
-        D, I, ranks, _ = self._csc.tfidf_query_end(min(int(k), self.n_docs, token[1]), doc_indices, want_scores=False)
-        return I, D, ranks
+        try:
+            D, I, ranks, _ = self._csc.tfidf_query_end(min(int(k), self.n_docs, token[1]), doc_indices,
+                                                       want_scores=False)
+            return I, D, ranks
+        finally:
+            self._release_begun()

@@ -57,6 +57,11 @@ def test_bad_word_and_empty_corpus(engine):
     from rag_system_amd.bm25 import device_postings
     with pytest.raises(ValueError):
         device_postings(np.array([0, 2]), np.array([1, 9], dtype=np.int32), 5)      # word 9 outside [0, 5)
+    with pytest.raises(ValueError):
+        device_postings(np.array([0, 2]), np.array([0, 0], dtype=np.int32), 0)      # tokens but an empty vocabulary
+    # the handle-less call leaves the library usable after a refused build (no copy pending into freed buffers)
+    tw, ip, rows, tf = device_postings(np.array([0, 2]), np.array([1, 1], dtype=np.int32), 5)
+    assert tw.tolist() == [1] and ip.tolist() == [0, 1] and rows.tolist() == [0] and tf.tolist() == [2.0]
     tw, ip, rows, tf = device_postings(np.array([0, 0, 0]), np.zeros(0, np.int32), 4)  # two empty documents
     assert len(tw) == 0 and ip.tolist() == [0] and len(rows) == 0
 

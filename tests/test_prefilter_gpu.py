@@ -105,6 +105,44 @@ def test_prefilter_rows_closer_than_a_bf16_rounding(engine, metric):
 
 
 @pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("side", [-1, 1])
+def test_prefilter_components_next_to_a_bf16_rounding_midpoint(engine, metric, side):
+    """Every component of the query and of half the rows sits just below (side = -1) or just above (+1) a
+    bfloat16 rounding midpoint, so ALL roundings go the same way: ||bf16(q)||^2 differs from ||q||^2 by the
+    full 2^-7 relative, the inner products of the copy are biased by the whole bound, and the cluster rows
+    (parallel to the query, closer together than a rounding) are indistinguishable in the copy.  The shadow's
+    L2 key holds the fp32 norms of both operands (sync_shadow, prepare_l2_norms), so the outside-row bound must
+    NOT be shifted by ||bf16(q)||^2 - ||q||^2 (with the shift the proof could close on a wrong
+    candidate set).  Ids must be those of the plain fp32 search."""
+    from rag_system_amd import faiss_compat as faiss
+    rng = np.random.default_rng(900 + metric + side)
+    d, n_cl, n_bg = 64, 20_000, 20_000
+    # bfloat16 keeps 8 significant bits: m * 2^e with m in [128, 256); midpoint of (m, m+1) = m + 0.5
+    m = rng.integers(128, 140, size=d).astype(np.float64)
+    qv = ((m + 0.5 + side * 2.0 ** -9) / 128.0 / np.sqrt(d)).astype(np.float32)
+    lens = 1.0 + 2e-4 * rng.standard_normal(n_cl)           # same direction, lengths inside one rounding step
+    cluster = (qv[None, :].astype(np.float64) * lens[:, None]).astype(np.float32)
+    X = np.concatenate([cluster, _rand_unit(rng, n_bg, d) * np.float32(np.linalg.norm(qv))])
+    X = X[rng.permutation(len(X))]
+    plain = faiss.IndexFlat(d, metric)
+    plain.add(X)
+    idx = faiss.IndexFlat(d, metric)
+    idx.add(X)
+    idx.set_prefilter(True)
+    for nq, k in [(1, 10), (3, 16), (20, 10), (100, 10)]:
+        Q = np.repeat(qv[None, :], nq, axis=0).copy()
+        Q[1:] *= (1.0 + 1e-4 * rng.standard_normal((nq - 1, 1))).astype(np.float32)
+        D0, I0 = _check(plain, X, Q, k, metric)
+        D1, I1 = _check(idx, X, Q, k, metric)
+        assert idx._b.last_kernel().startswith("prefilter")
+        same = I0 == I1
+        assert np.allclose(D0[~same], D1[~same], rtol=RTOL, atol=4e-6), (nq, k, int((~same).sum()))
+        assert np.allclose(D0, D1, rtol=RTOL, atol=4e-6)
+        # IP: the longest rows win and the copy cannot tell them apart; L2: the rows nearest in length
+        assert idx._b.prefilter_redone() >= 1, (nq, k)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
 def test_prefilter_one_long_row_and_nan(engine, metric):
     """max ||x|| enters the bound: one row 1000 times longer than the rest makes it useless (every query is
     redone), a NaN row makes it undefined (same).  Results still exact."""

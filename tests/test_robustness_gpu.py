@@ -247,3 +247,98 @@ def test_search_begin_end_equals_search_and_overlaps_sparse_scoring(engine):
         idx._b.search_end((1, 5))
     D2, I2 = idx.search(Q, 5)
     assert np.array_equal(I1, I2) or I2.max() >= n         # the ten new rows may now appear
+
+
+def test_concurrent_queries_through_the_split_search_paths(engine):
+    """search_rrf / search_hybrid / search_multi_representation run the dense pass and the TF-IDF
+    scoring through *_begin / *_end, and a handle takes one begun search.  The reference's UI starts one thread
+    per query (UI_manager.py:883): two threads on ONE SearchEngine must both get the results a single thread
+    gets (the second waits; nobody is refused), and a blocking index.search from a third thread waits too."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _data import zipf_queries
+    from test_host_logic import _build_store
+    from rag_system_amd.search_engine import SearchEngine
+    mgr, store, em = _build_store(n_docs=300, seed=41, dim=96)
+    eng = SearchEngine(store, em)
+    queries = [" ".join(t) for t in zipf_queries(8, 400, seed=5)]
+    methods = ("search_rrf", "search_hybrid", "search_multi_representation")
+    expected = {(m, q): getattr(eng, m)(q, top_k=10) for m in methods for q in queries}
+    errors, done = [], []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                for i, q in enumerate(queries):
+                    m = methods[(i + tid + rep) % len(methods)]
+                    got = getattr(eng, m)(q, top_k=10)
+                    assert got == expected[(m, q)], (tid, m, q)
+            done.append(tid)
+        except Exception as e:      # noqa: BLE001 -- reported below
+            errors.append((tid, repr(e)))
+
+    def plain_searcher():
+        try:
+            for q in queries * 6:
+                hits = store.search(em.embed_query(q), 5)
+                assert len(hits) == 5
+            done.append("plain")
+        except Exception as e:      # noqa: BLE001
+            errors.append(("plain", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)] + [threading.Thread(target=plain_searcher)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert sorted(map(str, done)) == ["0", "1", "2", "plain"]
+    # a thread that begins twice without ending is refused by the library, not dead-locked
+    from rag_system_amd import _lib
+    q = np.asarray(em.embed_query(queries[0]), np.float32).reshape(1, -1)
+    tok = store.index.search_begin(q, 5)
+    with pytest.raises(_lib.EngineError):
+        store.index.search_begin(q, 5)
+    store.index.search_end(tok)
+    assert store.index.search(q, 5)[1].shape == (1, 5)
+
+
+def test_flat_mmr_beside_adds_that_grow_the_arena(engine):
+    """rag_flat_mmr gathers candidate rows from the index arena; a concurrent rag_flat_add may
+    reallocate that arena (the reference's UI adds documents beside its query thread, UI_manager.py:753,883).
+    The selection runs under the handle's mutex until its kernel is enqueued, so every call returns the
+    selection of the (unchanged) candidate rows while the index grows 30-fold underneath."""
+    from rag_system_amd import faiss_compat as faiss
+    from rag_system_amd.candidates import mmr_select, mmr_select_stored
+    rng = np.random.default_rng(8)
+    d = 256
+    X0 = _rand_unit(rng, 4_000, d)
+    idx = faiss.IndexFlatIP(d)
+    idx.add(X0)
+    rows = rng.choice(4_000, 40, replace=False)
+    q = _rand_unit(rng, 1, d)[0]
+    blen = rng.integers(10, 500, 40)
+    expected = mmr_select(X0[rows], q, blen, 0.6, 12, 3000)
+    errors, stop = [], threading.Event()
+
+    def adder():
+        try:
+            for _ in range(30):
+                idx.add(_rand_unit(rng, 4_000, d))       # several of these outgrow the arena
+                idx.search(q.reshape(1, -1), 1)            # flush: the rows reach HBM now
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            stop.set()
+
+    t = threading.Thread(target=adder)
+    t.start()
+    n_calls = 0
+    while not stop.is_set() or n_calls < 50:
+        got = mmr_select_stored(idx, rows, q, blen, 0.6, 12, 3000)
+        assert got == expected, (n_calls, got, expected)
+        n_calls += 1
+    t.join(120)
+    assert not errors, errors
+    assert idx.ntotal == 4_000 * 31

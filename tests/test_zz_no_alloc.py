@@ -116,3 +116,32 @@ def test_noalloc_limits_and_errors(engine):
     l2 = faiss.IndexFlatL2(d)
     l2._b.add_synthetic(1000, 1, 0)                                 # rows in HBM, norms not computed yet
     assert call(l2._b._h, 1, 3) == _lib.RAG_ERR_UNSUPPORTED and b"norms" in lib.rag_last_error()
+
+
+def test_noalloc_on_another_stream_waits_for_the_row_norms(engine):
+    """the L2 row norms the no-allocation search reads are written by the EARLIER allocating search,
+    asynchronously on that search's stream.  Issued right behind it on another stream with no synchronisation
+    in between, the no-allocation search must still see them (it orders itself behind the handle's previous
+    search: event record + wait, nothing allocated)."""
+    import torch
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    d, n, k = 96, 400_000, 10
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    Q = _rand_unit(rng, 4, d)
+    for trial in range(3):
+        idx = faiss.IndexFlatL2(d)
+        idx._b.add_synthetic(n, 50 + trial, 0)                      # rows in HBM, norms not computed yet
+        qd = torch.from_numpy(Q).to(dev)
+        Da = torch.zeros((4, k), dtype=torch.float32, device=dev)
+        Ia = torch.zeros((4, k), dtype=torch.int64, device=dev)
+        Dn, In = torch.zeros_like(Da), torch.zeros_like(Ia)
+        torch.cuda.synchronize()
+        args = lambda D, I, s: (idx._b._h, 4, C.c_void_p(qd.data_ptr()), k, C.c_void_p(D.data_ptr()),  # noqa: E731
+                                C.c_void_p(I.data_ptr()), 0, C.c_void_p(s.cuda_stream))
+        _lib.check(lib.rag_flat_search_dev(*args(Da, Ia, sa)), lib)          # computes 400k norms on stream A
+        _lib.check(lib.rag_flat_search_dev_noalloc(*args(Dn, In, sb)), lib)  # reads them on stream B
+        torch.cuda.synchronize()
+        assert torch.equal(Ia, In) and torch.equal(Da.view(torch.int32), Dn.view(torch.int32)), trial
