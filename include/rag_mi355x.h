@@ -281,6 +281,37 @@ int rag_mmr(int C, int d, const float* cand, const float* q, double lambda, int 
 int rag_flat_mmr(rag_flat_t* h, int C, const int64_t* rows, const float* q, double lambda, int top_k,
                  const int64_t* byte_len, int64_t max_bytes, int32_t* out_order, int* out_n);
 
+/* The tail of a strategy=rrf query in ONE call (search_engine.py:340-347 reciprocal_rank_fusion over the three
+ * rankings + sort + cut, :121-129 knee cutoff and threshold of search_with_strategy, :131-133 / :396-468 MMR):
+ * one rank query, one single-workgroup kernel, one synchronisation -- the candidates never visit the host between
+ * the stages (rag_rrf, rag_tfidf_query_end and rag_flat_mmr are three synchronous calls for the same work; they
+ * stay, and tests compare this call with them bit for bit).
+ *   tfidf        a handle with a query BEGUN by rag_tfidf_query_begin with k >= top_k + (distinct documents of the
+ *                two rankings); this call ends it (on RAG_OK).  The full TF-IDF ranking of :332-336 enters as the
+ *                ranks of the candidates plus the head of the ranking, as rag_system_amd/search_engine.py derives.
+ *   dense_docs   the dense document ranking (best first, :321), each document as its ROW of the TF-IDF index, or
+ *                as a negative code of the caller's choice when it has none; bm25_docs the same for :322 (documents
+ *                may repeat; every entry counts, :356-358).  At most 128 entries each; top_k <= 64.
+ *   use_knee / threshold   as search_with_strategy's use_knee_detection / threshold.
+ *   flat, q, lambda, max_bytes   MMR over the entries that pass, with each document's embedding = the row of
+ *                `flat` named by rag_csc_set_doc_tables (mmr_selection(..., reuse_index_vectors=True)); flat NULL =
+ *                no MMR.  *mmr_done = 0 when some document has no such row (tables missing, -1, rows too long for
+ *                the kernel's LDS): the caller then runs mmr_selection on the kept entries itself.
+ * Outputs: fused_docs / fused_scores [top_k] with *n_fused entries, best first (codes as given, TF-IDF rows for
+ * documents of the head); *n_kept of them pass knee + threshold (a subsequence in the same order: recomputed by
+ * the caller from the scores); order [top_k] = *n_sel indices into the kept entries in MMR selection order.
+ * RAG_ERR_UNSUPPORTED (limits, too short a head, selection overflow) leaves the query begun: end it with
+ * rag_tfidf_query_end and take the three-call route. */
+int rag_hybrid_rrf_mmr(rag_csc_t* tfidf, rag_flat_t* flat, int n_dense, const int64_t* dense_docs, int n_bm25,
+                       const int64_t* bm25_docs, double k_const, int top_k, double threshold, int use_knee,
+                       const float* q, double lambda, int64_t max_bytes, int* n_fused, int64_t* fused_docs,
+                       double* fused_scores, int* n_kept, int* mmr_done, int* n_sel, int32_t* order);
+/* Side tables for rag_hybrid_rrf_mmr's MMR stage, one entry per row of the (TF-IDF) index: flat_row = the row of
+ * the flat index whose vector is the document's embedding (a document that is exactly one stored chunk:
+ * search_engine.py:415,418 would re-encode that very text), -1 = none; text_bytes = UTF-8 length of the text MMR
+ * budgets with (:437,:458).  Both NULL drops the tables.  Copied to HBM; refused while a query is begun. */
+int rag_csc_set_doc_tables(rag_csc_t* h, const int64_t* flat_row, const int64_t* text_bytes);
+
 #ifdef __cplusplus
 }
 #endif

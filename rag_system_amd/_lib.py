@@ -91,6 +91,9 @@ SIGNATURES = {
     "rag_rrf": (C.c_int, [C.c_int, _p, _p, C.c_double, _p, _p, _p]),
     "rag_mmr": (C.c_int, [C.c_int, C.c_int, _p, _p, C.c_double, C.c_int, _p, _i64, _p, _p]),
     "rag_flat_mmr": (C.c_int, [_p, C.c_int, _p, _p, C.c_double, C.c_int, _p, _i64, _p, _p]),
+    "rag_hybrid_rrf_mmr": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, _p, C.c_double, C.c_int, C.c_double, C.c_int, _p,
+                                     C.c_double, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "rag_csc_set_doc_tables": (C.c_int, [_p, _p, _p]),
 }
 
 _lock = threading.Lock()

@@ -123,6 +123,39 @@ class _HipCsc:
         return D[:k], I[:k], ranks, sc
 
 
+    def set_doc_tables(self, flat_row, text_bytes):
+        """rag_csc_set_doc_tables: per row, the flat-index row holding the document's embedding (-1: none) and
+        the UTF-8 length of its text; None, None drops the tables."""
+        if flat_row is None or text_bytes is None:
+            _lib.check(self._lib.rag_csc_set_doc_tables(self._h, None, None), self._lib)
+            return
+        fr = np.ascontiguousarray(flat_row, dtype=np.int64)
+        tb = np.ascontiguousarray(text_bytes, dtype=np.int64)
+        if len(fr) != self.n_rows or len(tb) != self.n_rows:
+            raise ValueError("doc tables need one entry per row (%d)" % self.n_rows)
+        _lib.check(self._lib.rag_csc_set_doc_tables(self._h, _lib.ptr(fr), _lib.ptr(tb)), self._lib)
+
+    def hybrid_tail(self, flat_backend, dense_docs, bm25_docs, k_const, top_k, threshold, use_knee, q, lam, max_bytes):
+        """rag_hybrid_rrf_mmr on this handle's begun query.  -> (fused_docs, fused_scores, n_kept, order or None),
+        or None when the engine does not serve the shape (the query stays begun: tfidf_query_end)."""
+        dd = np.ascontiguousarray(dense_docs, dtype=np.int64)
+        bd = np.ascontiguousarray(bm25_docs, dtype=np.int64)
+        fd = np.empty(max(top_k, 1), dtype=np.int64)
+        fs = np.empty(max(top_k, 1), dtype=np.float64)
+        order = np.empty(max(top_k, 1), dtype=np.int32)
+        nf, nk, done, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        qv = None if q is None else np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+        rc = self._lib.rag_hybrid_rrf_mmr(
+            self._h, flat_backend._h if flat_backend is not None else None, len(dd), _lib.ptr(dd), len(bd), _lib.ptr(bd),
+            float(k_const), int(top_k), float(threshold), 1 if use_knee else 0, _lib.ptr(qv), float(lam),
+            -1 if max_bytes is None else int(max_bytes), C.byref(nf), _lib.ptr(fd), _lib.ptr(fs), C.byref(nk),
+            C.byref(done), C.byref(ns), _lib.ptr(order))
+        if rc == _lib.RAG_ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc, self._lib)
+        return (fd[:nf.value], fs[:nf.value], nk.value, order[:ns.value].tolist() if done.value else None)
+
+
 _csc_factory = _HipCsc
 
 

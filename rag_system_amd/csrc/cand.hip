@@ -212,14 +212,13 @@ __global__ __launch_bounds__(CAND_THREADS) void rrf_sort_kernel(const long long*
 // candidate rows are read from (pinned / HBM) memory ONCE into LDS and every later phase works there; the same
 // float operations in the same order as the path through `nrm` / `simq` in HBM, four memory round trips fewer.
 constexpr size_t MMR_LDS_BYTES = 96 << 10;
+// (a __device__ body so that hybrid_tail_kernel below runs the very same selection behind its fusion; pointers
+// may address LDS: they are generic)
 template <bool STORED, bool LROWS>
-__global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restrict__ cand, const float* __restrict__ q,
-                                                           int C, int d, double lambda, int top_k,
-                                                           const long long* __restrict__ byte_len, long long max_bytes,
-                                                           float* __restrict__ nrm, float* __restrict__ G,
-                                                           float* __restrict__ simq, int* __restrict__ out_order,
-                                                           int* __restrict__ out_n, const long long* __restrict__ rows,
-                                                           const void* __restrict__ arena, int ld, int bf16) {
+__device__ __forceinline__ void mmr_body(const float* cand, const float* q, int C, int d, double lambda, int top_k,
+                                         const long long* byte_len, long long max_bytes, float* nrm, float* G,
+                                         float* simq, int* out_order, int* out_n, const long long* rows,
+                                         const void* arena, int ld, int bf16) {
     auto cval = [&](int i, int c) -> float {
         if (!STORED) return cand[(size_t)i * d + c];
         const size_t o = (size_t)rows[i] * ld + c;
@@ -426,6 +425,167 @@ __global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restri
         __syncthreads();
     }
     if (tid == 0) *out_n = n_sel;
+}
+
+template <bool STORED, bool LROWS>
+__global__ __launch_bounds__(CAND_THREADS) void mmr_kernel(const float* __restrict__ cand, const float* __restrict__ q,
+                                                           int C, int d, double lambda, int top_k,
+                                                           const long long* __restrict__ byte_len, long long max_bytes,
+                                                           float* __restrict__ nrm, float* __restrict__ G,
+                                                           float* __restrict__ simq, int* __restrict__ out_order,
+                                                           int* __restrict__ out_n, const long long* __restrict__ rows,
+                                                           const void* __restrict__ arena, int ld, int bf16) {
+    mmr_body<STORED, LROWS>(cand, q, C, d, lambda, top_k, byte_len, max_bytes, nrm, G, simq, out_order, out_n, rows, arena,
+                            ld, bf16);
+}
+
+// ---------------------------------------------------------------- hybrid tail (rag_hybrid_rrf_mmr)
+// Everything search_rrf does behind its three rankings, in ONE workgroup and one launch (search_engine.py:340-347,
+// :121-133, :396-468): RRF over the dense ranking, the BM25 ranking and the FULL TF-IDF ranking -- of which only the
+// ranks of the dense / BM25 candidates A (rank_one_kernel, enqueued just before) and the head (the begun query's
+// selection: the first top_k + |A| documents) can reach the result, rag_system_amd/search_engine.py -- the stable
+// descending sort, the cut to top_k, the knee cutoff and the threshold of search_with_strategy, and MMR over what
+// is left, with the documents' stored rows as embeddings (tables of rag_csc_set_doc_tables).  float64 sums in
+// Python's order, ties by dictionary insertion order: bit-identical to rag_rrf + host fusion + rag_flat_mmr.
+constexpr int HYB_MAX_LIST = 128;   // entries of the dense / of the BM25 ranking
+constexpr int HYB_MAX_A = 256;      // distinct candidates of the two
+constexpr int HYB_MAX_HEAD = 320;   // TF-IDF head entries (top_k + |A|)
+constexpr int HYB_MAX_TOPK = 64;
+struct HybArgs {
+    int n_dense, n_bm25, nA, n_head, top_k, use_knee, do_mmr;
+    int d, ld, bf16;
+    double k_const, threshold, lambda;
+    long long max_bytes, n_arena;
+    unsigned short dense_a[HYB_MAX_LIST], bm25_a[HYB_MAX_LIST];  // the rankings as indices into A
+    int a_row[HYB_MAX_A];   // TF-IDF row of candidate a, -1: the document has none
+    short a_rk[HYB_MAX_A];  // position of its rank in `ranks`, -1: none
+};
+struct HybOut {
+    int status;    // 0 ok, 1 = the head is not valid (selection overflow): nothing else was written
+    int n_fused;   // entries of the fused list (<= top_k), best first
+    int n_kept;    // of which pass the knee cutoff and the threshold (a subsequence, same order)
+    int mmr_done;  // 1: order / n_sel hold the MMR selection over the kept entries
+    int n_sel;
+    int pad[3];
+    int fa[HYB_MAX_TOPK];          // index into A, or -1: a document of the TF-IDF head
+    long long frow[HYB_MAX_TOPK];  // its TF-IDF row (-1: none)
+    double fscore[HYB_MAX_TOPK];
+    int order[HYB_MAX_TOPK];       // MMR: indices into the kept entries, in selection order
+};
+__global__ __launch_bounds__(CAND_THREADS) void hybrid_tail_kernel(
+    const HybArgs a, const long long* __restrict__ head_I, const int* __restrict__ overflow_flag,
+    const unsigned long long* __restrict__ ranks, const long long* __restrict__ doc_row,
+    const long long* __restrict__ doc_bytes, const float* __restrict__ q, const void* __restrict__ arena,
+    HybOut* __restrict__ out) {
+    constexpr int NF = HYB_MAX_A + HYB_MAX_HEAD;
+    __shared__ double s_score[NF];
+    __shared__ long long s_row[NF];
+    __shared__ unsigned char s_live[NF];
+    __shared__ int s_topf[HYB_MAX_TOPK];       // fused position -> entry
+    __shared__ long long s_mrow[HYB_MAX_TOPK], s_mbytes[HYB_MAX_TOPK];
+    __shared__ int s_nkept, s_mmr_ok, s_status;
+    const int tid = threadIdx.x;
+    const int nF = a.nA + a.n_head;
+    if (tid == 0) s_status = *overflow_flag != 0 ? 1 : 0;
+    for (int j = tid; j < a.n_head; j += CAND_THREADS) s_row[a.nA + j] = head_I[j];
+    for (int i = tid; i < a.nA; i += CAND_THREADS) s_row[i] = a.a_row[i];
+    __syncthreads();
+    if (s_status) {
+        if (tid == 0) out->status = 1;
+        return;
+    }
+    // scores: a candidate's terms in Python's order (dense ranking, BM25 ranking entry by entry, TF-IDF); a head
+    // document that is no candidate has its TF-IDF term only
+    for (int f = tid; f < nF; f += CAND_THREADS) {
+        double s = 0.0;
+        bool live = true;
+        if (f < a.nA) {
+            for (int j = 0; j < a.n_dense; ++j)
+                if (a.dense_a[j] == f) s = s + 1.0 / (a.k_const + (double)j);
+            for (int j = 0; j < a.n_bm25; ++j)
+                if (a.bm25_a[j] == f) s = s + 1.0 / (a.k_const + (double)j);
+            if (a.a_rk[f] >= 0) s = s + 1.0 / (a.k_const + (double)ranks[a.a_rk[f]]);
+        } else {
+            const long long r = s_row[f];
+            for (int i = 0; i < a.nA; ++i) live = live && s_row[i] != r;
+            s = 0.0 + 1.0 / (a.k_const + (double)(f - a.nA));
+        }
+        s_score[f] = s;
+        s_live[f] = live ? 1 : 0;
+    }
+    __syncthreads();
+    // stable descending order by counting (ties: dictionary insertion order = entry number); cut to top_k
+    int nlive = 0;
+    for (int f = 0; f < nF; ++f) nlive += s_live[f];   // (block-uniform; nF <= 576)
+    const int nfused = nlive < a.top_k ? nlive : a.top_k;
+    for (int f = tid; f < nF; f += CAND_THREADS) {
+        if (!s_live[f]) continue;
+        const double s = s_score[f];
+        int pos = 0;
+        for (int g = 0; g < nF; ++g) {
+            const double t = s_score[g];
+            pos += (s_live[g] && (t > s || (t == s && g < f))) ? 1 : 0;
+        }
+        if (pos < a.top_k) s_topf[pos] = f;
+    }
+    __syncthreads();
+    if (tid < nfused) {
+        const int f = s_topf[tid];
+        out->fa[tid] = f < a.nA ? f : -1;
+        out->frow[tid] = s_row[f];
+        out->fscore[tid] = s_score[f];
+    }
+    if (tid == 0) {
+        // search_with_strategy :121-129: (already sorted) knee cutoff with strict >, then threshold with >=
+        int kept[HYB_MAX_TOPK];
+        int nk = 0;
+        double cutoff = 0.0;
+        bool knee = a.use_knee != 0 && nfused > 0;
+        if (knee) {
+            if (nfused < 2) cutoff = s_score[s_topf[0]];
+            else {
+                int best = 0;
+                double bd = s_score[s_topf[0]] - s_score[s_topf[1]];
+                for (int i = 1; i < nfused - 1; ++i) {
+                    const double dd = s_score[s_topf[i]] - s_score[s_topf[i + 1]];
+                    if (dd > bd) {
+                        bd = dd;
+                        best = i;
+                    }
+                }
+                cutoff = s_score[s_topf[best + 1]];
+            }
+        }
+        for (int i = 0; i < nfused; ++i) {
+            const double s = s_score[s_topf[i]];
+            if (knee && !(s > cutoff)) continue;
+            if (!(s >= a.threshold)) continue;
+            kept[nk++] = i;
+        }
+        int ok = a.do_mmr != 0 && nk > 0 && doc_row != nullptr && doc_bytes != nullptr;
+        for (int i = 0; i < nk && ok; ++i) {
+            const long long r = s_row[s_topf[kept[i]]];
+            if (r < 0) {
+                ok = 0;
+                break;
+            }
+            const long long ar = doc_row[r];
+            if (ar < 0 || ar >= a.n_arena) ok = 0;
+            s_mrow[i] = ar;
+            s_mbytes[i] = doc_bytes[r];
+        }
+        s_nkept = nk;
+        s_mmr_ok = ok;
+        out->status = 0;
+        out->n_fused = nfused;
+        out->n_kept = nk;
+        out->mmr_done = ok;
+        if (!ok) out->n_sel = 0;
+    }
+    __syncthreads();
+    if (!s_mmr_ok) return;
+    mmr_body<true, true>(nullptr, q, s_nkept, a.d, a.lambda, a.top_k, s_mbytes, a.max_bytes, nullptr, nullptr, nullptr,
+                         out->order, &out->n_sel, s_mrow, arena, a.ld, a.bf16);
 }
 
 inline size_t al8(size_t b) { return (b + 7) & ~(size_t)7; }
@@ -642,6 +802,138 @@ int rag_flat_mmr(rag_flat_t* h, int C, const int64_t* rows, const float* q, doub
         return mmr_call(c.C, v.d, nullptr, reinterpret_cast<const long long*>(c.rows), v.arena, v.ld, v.bf16, c.q,
                         c.lambda, c.top_k, c.byte_len, c.max_bytes, c.out_order, c.out_n);
     }, &ctx);
+}
+
+
+int rag_hybrid_rrf_mmr(rag_csc_t* tfidf, rag_flat_t* flat, int n_dense, const int64_t* dense_docs, int n_bm25,
+                       const int64_t* bm25_docs, double k_const, int top_k, double threshold, int use_knee,
+                       const float* q, double lambda, int64_t max_bytes, int* n_fused, int64_t* fused_docs,
+                       double* fused_scores, int* n_kept, int* mmr_done, int* n_sel, int32_t* order) {
+    RAG_REQUIRE_INIT();
+    if (!tfidf || n_dense < 0 || n_bm25 < 0 || (n_dense > 0 && !dense_docs) || (n_bm25 > 0 && !bm25_docs) || top_k < 1 ||
+        !n_fused || !fused_docs || !fused_scores || !n_kept || !mmr_done || !n_sel || !order || (flat && !q))
+        return fail(RAG_ERR_INVALID_ARG, "rag_hybrid_rrf_mmr: bad argument");
+    *n_fused = *n_kept = *mmr_done = *n_sel = 0;
+    if (n_dense > HYB_MAX_LIST || n_bm25 > HYB_MAX_LIST || top_k > HYB_MAX_TOPK)
+        return fail(RAG_ERR_UNSUPPORTED, "rag_hybrid_rrf_mmr: rankings of %d / %d entries or top_k=%d beyond %d / %d / %d",
+                    n_dense, n_bm25, top_k, HYB_MAX_LIST, HYB_MAX_LIST, HYB_MAX_TOPK);
+    struct Ctx {
+        HybArgs a;
+        std::vector<long long> a_doc;  // the caller's code of candidate a
+        int rows[HYB_MAX_A];
+        int n_rows_q;
+        rag_flat_t* flat;
+        const float* q;
+        const CscBegunView* v;
+        bool* consumed;
+        int* n_fused; int64_t* fused_docs; double* fused_scores; int* n_kept; int* mmr_done; int* n_sel; int32_t* order;
+    } c;
+    std::memset(&c.a, 0, sizeof c.a);
+    c.n_rows_q = 0;
+    // A: distinct documents in first-appearance order (dense ranking, then BM25 ranking)
+    auto index_of = [&](long long doc) -> int {
+        for (size_t i = 0; i < c.a_doc.size(); ++i)
+            if (c.a_doc[i] == doc) return (int)i;
+        c.a_doc.push_back(doc);
+        return (int)c.a_doc.size() - 1;
+    };
+    for (int j = 0; j < n_dense; ++j) c.a.dense_a[j] = (unsigned short)index_of(dense_docs[j]);
+    for (int j = 0; j < n_bm25; ++j) c.a.bm25_a[j] = (unsigned short)index_of(bm25_docs[j]);
+    c.a.nA = (int)c.a_doc.size();
+    for (int i = 0; i < c.a.nA; ++i) {
+        const long long doc = c.a_doc[(size_t)i];
+        if (doc >= 0) {
+            if (doc > INT_MAX) return fail(RAG_ERR_INVALID_ARG, "rag_hybrid_rrf_mmr: document row %lld", doc);
+            c.a.a_row[i] = (int)doc;
+            c.a.a_rk[i] = (short)c.n_rows_q;
+            c.rows[c.n_rows_q++] = (int)doc;
+        } else {
+            c.a.a_row[i] = -1;
+            c.a.a_rk[i] = -1;
+        }
+    }
+    c.a.n_dense = n_dense;
+    c.a.n_bm25 = n_bm25;
+    c.a.top_k = top_k;
+    c.a.use_knee = use_knee;
+    c.a.k_const = k_const;
+    c.a.threshold = threshold;
+    c.a.lambda = lambda;
+    c.a.max_bytes = max_bytes;
+    c.flat = flat;
+    c.q = q;
+    c.n_fused = n_fused; c.fused_docs = fused_docs; c.fused_scores = fused_scores; c.n_kept = n_kept;
+    c.mmr_done = mmr_done; c.n_sel = n_sel; c.order = order;
+    bool consumed = false;
+    c.consumed = &consumed;
+
+    // innermost step: launch on the TF-IDF handle's stream, synchronise, hand the results over
+    auto run = [](Ctx& c, const void* arena) -> int {
+        const CscBegunView& v = *c.v;
+        CandWs& ws = cand_ws();
+        std::lock_guard<std::mutex> lk(ws.mu);
+        const size_t q_b = al8((size_t)std::max(c.a.d, 1) * sizeof(float));
+        int rc = ws.reserve(64, q_b + sizeof(HybOut));
+        if (rc) return rc;
+        float* hq = reinterpret_cast<float*>(ws.pin);
+        HybOut* ho = reinterpret_cast<HybOut*>(ws.pin + q_b);
+        if (c.a.do_mmr) std::memcpy(hq, c.q, (size_t)c.a.d * sizeof(float));
+        ho->status = -1;
+        const size_t smem = c.a.do_mmr ? ((size_t)c.a.top_k * c.a.d + c.a.d) * sizeof(float) : 0;
+        if (smem > 0) {
+            static bool attr_done = false;  // under ws.mu
+            if (!attr_done) {
+                RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_tail_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MMR_LDS_BYTES));
+                attr_done = true;
+            }
+        }
+        hybrid_tail_kernel<<<1, CAND_THREADS, smem, v.st>>>(c.a, v.head_I, v.overflow_flag, v.ranks, v.doc_row, v.doc_bytes,
+                                                           hq, arena, ho);
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipStreamSynchronize(v.st));
+        if (ho->status == 1)
+            return fail(RAG_ERR_UNSUPPORTED, "rag_hybrid_rrf_mmr: the TF-IDF selection overflowed (the query stays begun: "
+                                             "rag_tfidf_query_end serves it)");
+        if (ho->status != 0) return fail(RAG_ERR_HIP, "rag_hybrid_rrf_mmr: the kernel left no result");
+        *c.n_fused = ho->n_fused;
+        for (int i = 0; i < ho->n_fused; ++i) {
+            c.fused_docs[i] = ho->fa[i] >= 0 ? c.a_doc[(size_t)ho->fa[i]] : ho->frow[i];
+            c.fused_scores[i] = ho->fscore[i];
+        }
+        *c.n_kept = ho->n_kept;
+        *c.mmr_done = ho->mmr_done;
+        *c.n_sel = ho->mmr_done ? ho->n_sel : 0;
+        for (int i = 0; i < *c.n_sel; ++i) c.order[i] = ho->order[i];
+        *c.consumed = true;
+        return RAG_OK;
+    };
+    static int (*run_fn)(Ctx&, const void*) = run;
+
+    return csc_with_begun(tfidf, c.n_rows_q, c.rows, [](const CscBegunView& v, void* p) -> int {
+        Ctx& c = *static_cast<Ctx*>(p);
+        c.v = &v;
+        c.a.n_head = (int)std::min<long long>(std::min<long long>(v.begun_k, v.n_rows),
+                                              std::min<long long>((long long)c.a.top_k + c.a.nA, HYB_MAX_HEAD));
+        // the head must hold the first top_k + |A| documents of the ranking (or all of them)
+        if (c.a.n_head < std::min<long long>((long long)c.a.top_k + c.a.nA, v.n_rows))
+            return fail(RAG_ERR_UNSUPPORTED, "rag_hybrid_rrf_mmr: the begun query selected %d documents, %d are needed "
+                                             "(top_k + candidates)", v.begun_k, c.a.top_k + c.a.nA);
+        if (!c.flat) {
+            c.a.do_mmr = 0;
+            return run_fn(c, nullptr);
+        }
+        return flat_with_view(c.flat, [](const FlatView& fv, void* p2) -> int {
+            Ctx& c = *static_cast<Ctx*>(p2);
+            c.a.d = fv.d;
+            c.a.ld = fv.ld;
+            c.a.bf16 = fv.bf16;
+            c.a.n_arena = fv.n_rows;
+            // the rows of top_k candidates and the query must fit the kernel's LDS image; else fusion only
+            c.a.do_mmr = ((size_t)c.a.top_k * fv.d + fv.d) * sizeof(float) <= MMR_LDS_BYTES ? 1 : 0;
+            return run_fn(c, fv.arena);
+        }, &c);
+    }, &c, &consumed);
 }
 
 }  // extern "C"

@@ -57,6 +57,20 @@ struct FlatView {
     int64_t n_rows;
 };
 int flat_with_view(rag_flat_t* h, int (*use)(const FlatView&, void*), void* ctx);
+// sparse.hip: a begun TF-IDF query (rag_tfidf_query_begin) seen by rag_hybrid_rrf_mmr (cand.hip)
+struct CscBegunView {
+    hipStream_t st;                   // the handle's own stream: scoring + selection are enqueued there
+    int begun_k;                      // entries of the selected head
+    int64_t n_rows;
+    const double* head_D;             // pinned host memory, written by the selection kernel: the begun_k best scores
+    const long long* head_I;          //   and their rows, in ranking order
+    const int* overflow_flag;         // pinned: != 0 -> the head is not valid (selection buffer overflow)
+    const unsigned long long* ranks;  // HBM: ranks of the rows given to csc_with_begun, in their order
+    const long long* doc_row;         // HBM tables of rag_csc_set_doc_tables, or nullptr
+    const long long* doc_bytes;
+};
+int csc_with_begun(rag_csc_t* h, int n_query, const int* rows, int (*use)(const CscBegunView&, void*), void* ctx,
+                   bool* consumed);
 int flat_init_scratch();  // flat.hip: address of the no-allocation entry point's scratch on the current device
 
 }  // namespace rag

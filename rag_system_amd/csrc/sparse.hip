@@ -1185,6 +1185,10 @@ struct rag_csc {
     hipStream_t own_st = nullptr;
     int begun_k = 0;
     unsigned long long* rk1_hist = nullptr;  // rank_one_kernel: [RANK1_HREP][RANK1_MAXQ] bins + ticket word behind them, zero between calls
+    // rag_csc_set_doc_tables (rag_hybrid_rrf_mmr): per row of this index, the row of a flat index that holds the
+    // document's embedding (-1: none) and the byte length of its text
+    long long* doc_row = nullptr;
+    long long* doc_bytes = nullptr;
     std::mutex mu;
 };
 
@@ -1505,6 +1509,8 @@ void rag_csc_free(rag_csc_t* h) {
     (void)hipFree(h->rk_hist);
     (void)hipFree(h->rk_gather);
     (void)hipFree(h->rk1_hist);
+    (void)hipFree(h->doc_row);
+    (void)hipFree(h->doc_bytes);
     (void)hipFree(h->skip);
     (void)hipFree(h->wmax);
     (void)hipFree(h->bmax);
@@ -1769,6 +1775,28 @@ int rag_tfidf_query_end(rag_csc_t* h, int k, double* D, int64_t* I, int n_query,
     return RAG_OK;
 }
 
+int rag_csc_set_doc_tables(rag_csc_t* h, const int64_t* flat_row, const int64_t* text_bytes) {
+    RAG_REQUIRE_INIT();
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "bad handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "a TF-IDF query is begun on this handle: end it first");
+    if (h->own_st) RAG_HIP(hipStreamSynchronize(h->own_st));
+    if (!flat_row || !text_bytes) {  // drop the tables
+        if (h->doc_row) RAG_HIP(hipFree(h->doc_row));
+        if (h->doc_bytes) RAG_HIP(hipFree(h->doc_bytes));
+        h->doc_row = h->doc_bytes = nullptr;
+        return RAG_OK;
+    }
+    const size_t b = (size_t)std::max<int64_t>(h->n_rows, 1) * sizeof(long long);
+    if (!h->doc_row) RAG_HIP(hipMalloc(&h->doc_row, b));
+    if (!h->doc_bytes) RAG_HIP(hipMalloc(&h->doc_bytes, b));
+    if (h->n_rows > 0) {
+        RAG_HIP(hipMemcpy(h->doc_row, flat_row, (size_t)h->n_rows * sizeof(long long), hipMemcpyHostToDevice));
+        RAG_HIP(hipMemcpy(h->doc_bytes, text_bytes, (size_t)h->n_rows * sizeof(long long), hipMemcpyHostToDevice));
+    }
+    return RAG_OK;
+}
+
 int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks) {
     RAG_REQUIRE_INIT();
     if (!h || n_query < 0 || (n_query > 0 && (!rows || !ranks))) return fail(RAG_ERR_INVALID_ARG, "bad argument");
@@ -1823,3 +1851,50 @@ int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_s
 }
 
 }  // extern "C"
+
+namespace rag {
+// cand.hip (rag_hybrid_rrf_mmr): the begun TF-IDF query of `h` seen from outside.  Runs with the handle's mutex
+// held: enqueues the rank query of `rows` (rank_one_kernel, ranks left in HBM) on the handle's own stream behind the
+// begun scoring + selection, then calls `use`, which enqueues its own kernel on view.st, synchronises and reads its
+// results.  *consumed (set by `use`) = the query is over; otherwise it stays begun (rag_tfidf_query_end ends it).
+int csc_with_begun(rag_csc_t* h, int n_query, const int* rows, int (*use)(const CscBegunView&, void*), void* ctx,
+                   bool* consumed) {
+    *consumed = false;
+    if (!h || n_query < 0 || n_query > RANK1_MAXQ || (n_query > 0 && !rows)) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->begun_k) return fail(RAG_ERR_INVALID_ARG, "no TF-IDF query begun on this handle (rag_tfidf_query_begin)");
+    for (int i = 0; i < n_query; ++i)
+        if (rows[i] < 0 || rows[i] >= h->n_rows)
+            return fail(RAG_ERR_INVALID_ARG, "row %d outside [0,%lld)", rows[i], (long long)h->n_rows);
+    hipStream_t st = h->own_st;
+    if (n_query > 0) {
+        if (!h->rk1_hist) {
+            RAG_HIP(hipMalloc(&h->rk1_hist, (RANK1_HREP * RANK1_MAXQ + 8) * sizeof(unsigned long long)));
+            RAG_HIP(hipMemset(h->rk1_hist, 0, (RANK1_HREP * RANK1_MAXQ + 8) * sizeof(unsigned long long)));
+        }
+        const long long nb1 = std::max<long long>(1, std::min<long long>((h->n_rows + RANK1_T * RANK1_RB - 1) / (RANK1_T * RANK1_RB),
+                                                                         (long long)num_cus()));
+        Rank1Rows qr;
+        for (int i = 0; i < n_query; ++i) qr.r[i] = rows[i];
+        rank_one_kernel<<<(unsigned)nb1, RANK1_T, 0, st>>>(h->score, (long long)h->n_rows, n_query, qr, h->rk1_hist,
+                                                          reinterpret_cast<int*>(h->rk1_hist + RANK1_HREP * RANK1_MAXQ),
+                                                          h->rk_out, nullptr);
+        RAG_HIP(hipGetLastError());
+    }
+    CscBegunView v;
+    v.st = st;
+    v.begun_k = h->begun_k;
+    v.n_rows = h->n_rows;
+    v.head_D = reinterpret_cast<const double*>(h->pin);
+    v.head_I = reinterpret_cast<const long long*>(h->pin + PIN_BYTES / 2);
+    v.overflow_flag = reinterpret_cast<const int*>(h->pin + PIN_FLAG);
+    v.ranks = h->rk_out;
+    v.doc_row = h->doc_row;
+    v.doc_bytes = h->doc_bytes;
+    const int rc = use(v, ctx);
+    // whatever `use` did, nothing of this call is left running on the stream
+    (void)hipStreamSynchronize(st);
+    if (rc == RAG_OK && *consumed) h->begun_k = 0;
+    return rc;
+}
+}  // namespace rag

@@ -188,6 +188,45 @@ class TfidfScorer:
         finally:
             self._release_begun()
 
+    def set_doc_tables(self, flat_row, text_bytes):
+        """Side tables for hybrid_tail's MMR stage (rag_csc_set_doc_tables); False when the backend has none."""
+        fn = getattr(self._csc, "set_doc_tables", None)
+        if fn is None:
+            return False
+        with self._serialised():
+            fn(flat_row, text_bytes)
+        return True
+
+    def hybrid_tail(self, token, flat_index, dense_docs, bm25_docs, top_k, k_const=60, threshold=None, use_knee=False,
+                    q=None, lam=0.5, max_bytes=None):
+        """The rest of a strategy=rrf query behind a begun query in one engine call (rag_hybrid_rrf_mmr): RRF with
+        the full TF-IDF ranking, sort, cut to top_k, knee / threshold, MMR on stored rows.
+        -> (fused_docs, fused_scores, n_kept, mmr_order or None); None = not served, the query is STILL begun
+        (use query_end).  threshold None = no threshold filter."""
+        fn = getattr(self._csc, "hybrid_tail", None)
+        if fn is None or token is None:
+            return None
+        backend = getattr(flat_index, "_b", flat_index) if flat_index is not None else None
+        if backend is not None and not hasattr(backend, "_h"):
+            backend = None
+        try:
+            out = fn(backend, dense_docs, bm25_docs, k_const, top_k, -float("inf") if threshold is None else threshold,
+                     use_knee, q, lam, max_bytes)
+        except BaseException:
+            self._abort_quietly()
+            raise
+        if out is not None:
+            self._release_begun()
+        return out
+
+    def _abort_quietly(self):
+        try:
+            self._csc.tfidf_query_abort()
+        except Exception:
+            pass
+        finally:
+            self._release_begun()
+
     def query_abort(self, token):
         """Give up a begun query (the handle accepts other calls again)."""
         try:
