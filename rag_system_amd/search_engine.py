@@ -35,6 +35,14 @@ def _rank_key(r):
     return r.get("ce_score", r.get("score", 0.0))
 
 
+class _Begun:
+    """A begun dense search: the store's token and the query embedding it was begun with."""
+    __slots__ = ("tok", "q_vec")
+
+    def __init__(self, tok, q_vec):
+        self.tok, self.q_vec = tok, q_vec
+
+
 class SearchEngine:
     def __init__(self, vector_storage, embedding_manager, cross_encoder=None, weight_dense=0.4, weight_bm25=0.3,
                  weight_tfidf=0.3, verbose=False):
@@ -68,7 +76,22 @@ class SearchEngine:
         elif strategy == "multi":
             results = self.search_multi_representation(query, top_k, "document")
         elif strategy == "rrf":
-            results = self.search_rrf(query, top_k, "document")
+            # everything behind the three rankings -- fusion, sort, cut, knee, threshold and (with
+            # mmr_reuse_index_vectors) MMR -- in one engine call when it is served (rag_hybrid_rrf_mmr)
+            post = None
+            if not self.cross_encoder:
+                post = {"threshold": threshold, "knee": bool(use_knee_detection),
+                        "mmr": bool(use_mmr and mmr_reuse_index_vectors), "lambda": mmr_lambda,
+                        "max_bytes": max_context_bytes}
+            results, final = self._search_rrf(query, top_k, post)
+            if final is not None:
+                kept, order = final
+                if not use_mmr or not kept:
+                    return kept
+                if order is not None:
+                    return [kept[i] for i in order]
+                return self.mmr_selection(query, kept, self.embedding_manager, lambda_param=mmr_lambda, top_k=top_k,
+                                          max_context_bytes=max_context_bytes, reuse_index_vectors=mmr_reuse_index_vectors)
         else:
             raise ValueError(f"Unknown retrieval strategy: {strategy}")
         results.sort(key=_rank_key, reverse=True)
@@ -108,12 +131,12 @@ class SearchEngine:
         q_vec = self.embedding_manager.embed_query(query)
         vs = self.vector_storage
         if hasattr(vs, "search_begin"):
-            return vs.search_begin(q_vec, top_k=k)
-        return ("done", vs.search(q_vec, top_k=k))
+            return _Begun(vs.search_begin(q_vec, top_k=k), q_vec)
+        return _Begun(("done", vs.search(q_vec, top_k=k)), q_vec)
 
     def _dense_chunks_end(self, token):
         vs = self.vector_storage
-        hits = vs.search_end(token) if hasattr(vs, "search_end") else token[1]
+        hits = vs.search_end(token.tok) if hasattr(vs, "search_end") else token.tok[1]
         for r in hits:
             r["score"] = float(r["score"])
         return hits
@@ -141,14 +164,20 @@ class SearchEngine:
         k = top_k * 3 if retrieval_mode == "document" else top_k
         return (self._dense_chunks_begin(query, k), query, top_k, retrieval_mode)
 
-    def _search_faiss_end(self, pending):
+    def _search_faiss_end(self, pending, want_text=True):
+        """want_text=False (fusion strategies without a cross-encoder): the joined chunk texts of the document
+        ranking are never looked at again (the fused entries get the full document text, :343-345), so they
+        are not built."""
         if pending is None:
             return []
         token, query, top_k, retrieval_mode = pending
         hits = self._dense_chunks_end(token)
         if retrieval_mode == "document":
             groups = self._group_dense_by_doc(hits)
-            results = [{"doc_id": d, "score": g["score"], "text": " ".join(g["chunks"])} for d, g in groups.items()]
+            if want_text or self.cross_encoder:
+                results = [{"doc_id": d, "score": g["score"], "text": " ".join(g["chunks"])} for d, g in groups.items()]
+            else:
+                results = [{"doc_id": d, "score": g["score"]} for d, g in groups.items()]
         else:
             results = hits
         if self.cross_encoder:
@@ -182,12 +211,14 @@ class SearchEngine:
             out.append(results[:top_k])
         return out
 
-    def search_bm25(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
+    def search_bm25(self, query: str, top_k=10, retrieval_mode="document", _want_text=True) -> List[Dict[str, Any]]:
         if "bm25" not in self.vector_storage.indices_present:
             return []
         hits = self.vector_storage.search_bm25(query, top_k=top_k)
         if retrieval_mode == "document":
             # one entry per chunk hit, doc ids may repeat
+            if not _want_text and not self.cross_encoder:     # fusion strategies: only ids and scores are used
+                return [{"doc_id": r["doc_id"], "score": r["score"]} for r in hits]
             docs = [{"doc_id": r["doc_id"], "score": r["score"], "text": self._doc_text(r["doc_id"])} for r in hits]
             if self.cross_encoder:
                 docs = self.rerank_with_cross_encoder(query, docs, normalize_ce=False)
@@ -276,11 +307,7 @@ class SearchEngine:
         if scorer is None:
             self._tfidf_abort(begun)
             return None
-        pos = getattr(self.vector_storage, "_tfidf_pos", None)
-        if pos is None or pos[0] is not doc_ids or len(pos[1]) != len(doc_ids):
-            pos = (doc_ids, {d: i for i, d in enumerate(doc_ids)})
-            self.vector_storage._tfidf_pos = pos
-        pos = pos[1]
+        pos = self._tfidf_rows(None) or {}
         rows = [pos[d] for d in cand_doc_ids if d in pos]
         k = min(n_extra, len(doc_ids))
         if begun is not None and begun[0] is scorer and k <= begun[1][1] and rows:
@@ -297,13 +324,13 @@ class SearchEngine:
         pending = self._search_faiss_begin(query, top_k * 3, "document")
         tf_begun = self._tfidf_begin(query, top_k * 7)     # beside the dense pass, like the BM25 scoring below
         try:
-            bm25_hits = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+            bm25_hits = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document", _want_text=False)
         except Exception:
             self._tfidf_abort(tf_begun)
             self._dense_abort(pending[0] if pending else None)
             raise
         try:
-            dense = {d["doc_id"]: d["score"] for d in self._search_faiss_end(pending)}
+            dense = {d["doc_id"]: d["score"] for d in self._search_faiss_end(pending, want_text=False)}
         except Exception:
             self._tfidf_abort(tf_begun)
             raise
@@ -332,9 +359,11 @@ class SearchEngine:
         for doc_id in dict.fromkeys(list(dn) + list(bn) + list(tn)):
             fused = (self.weight_dense * dn.get(doc_id, 0) + self.weight_bm25 * bn.get(doc_id, 0)
                      + self.weight_tfidf * tn.get(doc_id, 0))
-            results.append({"doc_id": doc_id, "score": fused, "text": self._doc_text(doc_id)})
+            results.append({"doc_id": doc_id, "score": fused})
         results.sort(key=lambda x: x["score"], reverse=True)
         results = results[:top_k]
+        for r in results:                   # the text only for what survives the cut (stable sort: same order)
+            r["text"] = self._doc_text(r["doc_id"])
         if self.cross_encoder:
             results = self.rerank_with_cross_encoder(query, results, normalize_ce=True)
         return results
@@ -342,17 +371,60 @@ class SearchEngine:
     # ------------------------------------------------------------------ rrf
 
     def search_rrf(self, query: str, top_k=10, retrieval_mode="document") -> List[Dict[str, Any]]:
+        return self._search_rrf(query, top_k, None)[0]
+
+    def _tfidf_rows(self, doc_ids):
+        """TF-IDF row of every doc id (built once per store), or None without a TF-IDF index."""
+        vs = self.vector_storage
+        doc_list = getattr(vs, "tfidf_doc_ids", None)
+        if not doc_list:
+            return None
+        pos = getattr(vs, "_tfidf_pos", None)
+        if pos is None or pos[0] is not doc_list or len(pos[1]) != len(doc_list):
+            pos = (doc_list, {d: i for i, d in enumerate(doc_list)})
+            vs._tfidf_pos = pos
+        return pos[1]
+
+    def _search_rrf(self, query, top_k, post):
+        """search_rrf (:320-350).  post = None: plain.  post = {threshold, knee, mmr, lambda, max_bytes} (from
+        search_with_strategy, no cross-encoder): what follows the fusion there (:121-133) may run in the same
+        engine call; then the second return value is (kept results, MMR order or None), else it is None and
+        the first is search_rrf's result."""
+        tables_ok = False
+        if post is not None and post["mmr"]:
+            # the MMR side tables are uploaded once per store, and before a TF-IDF query is begun
+            try:
+                tables = getattr(self.vector_storage, "hybrid_doc_tables", None)
+                tables_ok = bool(tables is not None and tables(self.vector_storage.get_tfidf_scorer()))
+            except Exception as e:
+                self._debug("hybrid_doc_tables failed: %s" % e)
         pending = self._search_faiss_begin(query, top_k * 3, "document")
         tf_begun = self._tfidf_begin(query, top_k * 7)     # beside the dense pass, like the BM25 scoring below
         try:
-            bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document")
+            bm25_ranking = self.search_bm25(query, top_k=top_k * 3, retrieval_mode="document", _want_text=False)
         except Exception:
             self._tfidf_abort(tf_begun)
             self._dense_abort(pending[0] if pending else None)
             raise
         try:
-            dense_ranking = self._search_faiss_end(pending)
-            fused = self.reciprocal_rank_fusion(dense_ranking, bm25_ranking, k=60)
+            dense_ranking = self._search_faiss_end(pending, want_text=False)
+        except Exception:
+            self._tfidf_abort(tf_begun)
+            raise
+        ordered = [[r["doc_id"] for r in sorted(ranking, key=lambda x: x["score"], reverse=True)]
+                   for ranking in (dense_ranking, bm25_ranking)]
+        # ---- one engine call for everything behind the rankings (rag_hybrid_rrf_mmr), when it is served
+        if tf_begun is not None:
+            try:
+                done = self._rrf_tail(query, top_k, post, pending, tf_begun, ordered, tables_ok)
+            except Exception:
+                self._tfidf_abort(tf_begun)
+                raise
+            if done is not None:
+                return done
+        # ---- the three-call route: rag_rrf, TF-IDF rank query, fusion on the host
+        try:
+            fused = candidates.reciprocal_rank_fusion(ordered, k=60)
         except Exception:
             self._tfidf_abort(tf_begun)
             raise
@@ -365,12 +437,58 @@ class SearchEngine:
             for rank, doc_id in enumerate(top_ids):    # the head of the TF-IDF ranking, in ranking order
                 if doc_id not in fused:
                     fused[doc_id] = 0 + 1.0 / (60 + rank)
-        combined = [{"doc_id": d, "score": s, "text": self._doc_text(d)} for d, s in fused.items()]
-        combined.sort(key=lambda x: x["score"], reverse=True)
-        combined = combined[:top_k]
+        combined = sorted(fused.items(), key=lambda kv: kv[1], reverse=True)[:top_k]     # stable, like :346-347
+        combined = [{"doc_id": d, "score": s, "text": self._doc_text(d)} for d, s in combined]
         if self.cross_encoder:
             combined = self.rerank_with_cross_encoder(query, combined, normalize_ce=True)
-        return combined
+        return combined, None
+
+    def _rrf_tail(self, query, top_k, post, pending, tf_begun, ordered, tables_ok=False):
+        """The fused tail.  None = not served (the TF-IDF query is still begun); else _search_rrf's result."""
+        scorer, tok = tf_begun
+        if not hasattr(scorer, "hybrid_tail") or top_k > 64 or len(ordered[0]) > 128 or len(ordered[1]) > 128:
+            return None
+        pos = self._tfidf_rows(None)
+        if pos is None:
+            return None
+        doc_list = self.vector_storage.tfidf_doc_ids
+        extra = {}                                      # documents without a TF-IDF row: codes -1, -2, ...
+        rows = [[pos[d] if d in pos else -1 - extra.setdefault(d, len(extra)) for d in ranking] for ranking in ordered]
+        n_cand = len(set(rows[0]) | set(rows[1]))
+        if top_k + n_cand > tok[1] and tok[1] < len(doc_list):
+            return None                                 # the begun selection is too short for this candidate set
+        in_kernel = post is not None
+        flat = q_vec = None
+        if in_kernel and post["mmr"] and tables_ok:
+            flat = self.vector_storage.index
+            q_vec = np.asarray(pending[0].q_vec, dtype="float32").reshape(-1) if pending else None
+            if q_vec is None:
+                q_vec = np.asarray(self.embedding_manager.embed_query(query), dtype="float32").reshape(-1)
+        out = scorer.hybrid_tail(tok, flat, rows[0], rows[1], top_k, 60,
+                                 post["threshold"] if in_kernel else None, post["knee"] if in_kernel else False,
+                                 q_vec, post["lambda"] if in_kernel else 0.5, post["max_bytes"] if in_kernel else None)
+        if out is None:
+            return None
+        fd, fs, n_kept, order = out
+        back = {-1 - j: d for d, j in extra.items()}
+        combined = []
+        for code, sc in zip(fd.tolist(), fs.tolist()):
+            d = doc_list[code] if code >= 0 else back[code]
+            combined.append({"doc_id": d, "score": sc, "text": self._doc_text(d)})
+        if self.cross_encoder:
+            combined = self.rerank_with_cross_encoder(query, combined, normalize_ce=True)
+        if not in_kernel:
+            return combined, None
+        # what search_with_strategy does behind the strategy (:121-129), recomputed here from the same float64
+        # scores; the kernel's count must agree (it ran MMR over exactly these entries)
+        kept = combined
+        if post["knee"] and kept:
+            cutoff = detect_knee([r["score"] for r in kept])
+            kept = [r for r in kept if r["score"] > cutoff]
+        kept = [r for r in kept if r["score"] >= post["threshold"]]
+        if len(kept) != n_kept:
+            raise RuntimeError("rag_hybrid_rrf_mmr kept %d entries, the host rule keeps %d" % (n_kept, len(kept)))
+        return combined, (kept, order)
 
     def reciprocal_rank_fusion(self, *rankings, k=60) -> Dict[str, float]:
         """rrf[doc] += 1/(k+rank) over every entry of every ranking (each sorted by score, stable);
@@ -444,7 +562,9 @@ class SearchEngine:
             return None
         rows = []
         for r in results:
-            i = cache[1].get((r.get("doc_id"), r["chunk"])) if "chunk" in r else None
+            # a chunk hit, or a document entry whose text IS one stored chunk (a one-chunk document: the text
+            # :415 hands to model.encode is exactly that chunk's)
+            i = cache[1].get((r.get("doc_id"), r.get("chunk", r.get("text"))))
             if i is None:
                 return None
             rows.append(i)

@@ -219,6 +219,34 @@ class VectorStorage:
             self._tfidf_scorer_key = key
         return self._tfidf_scorer
 
+    def hybrid_doc_tables(self, scorer):
+        """Side tables of rag_hybrid_rrf_mmr's MMR stage for the current indices, uploaded once (SURVEY 8(f) f4
+        on the device): per TF-IDF row, the row of the dense index that IS the document's embedding -- a
+        document with exactly one stored chunk, whose text mmr_selection would re-encode (search_engine.py:415,
+        :418) -- else -1, and the UTF-8 length of the document text (:437, :458).  False when the dense index
+        and chunks_data are out of step or the scorer has no such call."""
+        if scorer is None or not hasattr(scorer, "set_doc_tables") or self.index.ntotal != len(self.chunks_data):
+            return False
+        key = (id(scorer), id(self.tfidf_doc_ids), len(self.tfidf_doc_ids), len(self.chunks_data), id(self.index))
+        if getattr(self, "_hybrid_tables_key", None) == key:
+            return self._hybrid_tables_ok
+        first_row, n_chunks = {}, {}
+        for i, cd in enumerate(self.chunks_data):
+            d = cd["doc_id"]
+            n_chunks[d] = n_chunks.get(d, 0) + 1
+            first_row.setdefault(d, i)
+        flat_row = np.full(len(self.tfidf_doc_ids), -1, dtype=np.int64)
+        text_bytes = np.zeros(len(self.tfidf_doc_ids), dtype=np.int64)
+        for r, d in enumerate(self.tfidf_doc_ids):
+            chunks = self.documents.get(d, {}).get("chunks", [])
+            text_bytes[r] = len(" ".join(ch["chunk"] for ch in chunks).encode("utf-8"))
+            # the document's text must be the text of the one chunk the index holds for it
+            if n_chunks.get(d) == 1 and len(chunks) == 1 and chunks[0]["chunk"] == self.chunks_data[first_row[d]]["chunk"]:
+                flat_row[r] = first_row[d]
+        self._hybrid_tables_ok = bool(scorer.set_doc_tables(flat_row, text_bytes))
+        self._hybrid_tables_key = key
+        return self._hybrid_tables_ok
+
     # ---- maintenance ------------------------------------------------------------------
 
     def rebuild_all_indices(self, embedding_manager):

@@ -166,3 +166,88 @@ def test_hybrid_tail_limits_and_fallbacks(engine):
     assert out[1].tolist() == [1.0 / (60 + r) for r in range(10)]
     # a call without a begun query
     assert ts.hybrid_tail(None, None, dense, bm25, 10) is None
+
+
+def _product_store(n_docs=400, dim=96, seed=3):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _data import zipf_corpus
+    from rag_system_amd.text import HashingEmbeddingManager
+    from rag_system_amd.vector_storage import VectorStorageManager
+    em = HashingEmbeddingManager(dim=dim, chunk_size=90, overlap=10)
+    store = VectorStorageManager().create_storage("s", dim, embedder=em.model_name)
+    docs = zipf_corpus(n_docs, 300, 25, seed=seed)          # nearly every document is one chunk ...
+    for i in range(0, n_docs, 40):                           # ... and every 40th is long enough for several
+        docs[i] = list(docs[i]) * 12
+    docs[9] = list(docs[4])                                  # duplicate document: exact ties in every signal
+    n_single = 0
+    for i, toks in enumerate(docs):
+        chunks, emb = em.embed_text(" ".join(toks), doc_name="doc%d.txt" % i)
+        n_single += len(chunks) == 1
+        for ch, e in zip(chunks, emb):
+            store.add_vector(e, "doc%d" % i, ch["chunk"], ch["source"])
+    store.rebuild_bm25_index()
+    store.rebuild_tfidf_index()
+    assert 0.8 * n_docs < n_single < n_docs, n_single
+    return store, em
+
+
+def test_search_engine_rrf_through_the_one_call_tail_equals_the_three_call_route(engine):
+    """SearchEngine.search_with_strategy("rrf", ...) takes rag_hybrid_rrf_mmr for everything behind the three
+    rankings -- incl. knee / threshold and, with mmr_reuse_index_vectors, MMR on the stored rows of one-chunk
+    documents.  Same result lists as the three-call route (the tail switched off), entry for entry, and as
+    search_rrf + mmr_selection(reuse_index_vectors=True) called separately."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _data import zipf_queries
+    from rag_system_amd.search_engine import SearchEngine
+    store, em = _product_store()
+    eng = SearchEngine(store, em)
+    slow = SearchEngine(store, em)
+    slow._rrf_tail = lambda *a, **k: None                   # the three-call route
+    calls = {"tail": 0, "mmr_in_kernel": 0, "encode": 0}
+    scorer = store.get_tfidf_scorer()
+    real_tail = scorer.hybrid_tail
+
+    def counting_tail(*a, **k):
+        out = real_tail(*a, **k)
+        calls["tail"] += out is not None
+        calls["mmr_in_kernel"] += out is not None and out[3] is not None
+        return out
+    scorer.hybrid_tail = counting_tail
+    real_encode = em.model.encode
+
+    def counting_encode(texts, *a, **k):
+        if not isinstance(texts, str):
+            calls["encode"] += 1
+        return real_encode(texts, *a, **k)
+    em.model.encode = counting_encode
+    queries = [" ".join(t) for t in zipf_queries(10, 300, seed=12)] + ["zzzz qqqq", store.chunks_data[3]["chunk"][:50]]
+    try:
+        for q in queries:
+            for top_k in (3, 10):
+                assert eng.search_rrf(q, top_k=top_k) == slow.search_rrf(q, top_k=top_k)
+                for kw in ({}, {"use_knee_detection": True}, {"threshold": 0.02}, {"threshold": 0.018, "use_knee_detection": True},
+                           {"use_mmr": True}, {"use_mmr": True, "mmr_reuse_index_vectors": True, "mmr_lambda": 0.7},
+                           {"use_mmr": True, "mmr_reuse_index_vectors": True, "max_context_bytes": 900, "threshold": 0.017},
+                           {"use_mmr": True, "mmr_reuse_index_vectors": True, "use_knee_detection": True}):
+                    n0 = calls["tail"]
+                    got = eng.search_with_strategy(q, "rrf", top_k, **kw)
+                    assert calls["tail"] == n0 + 1, "the one-call tail was not taken"
+                    exp = slow.search_with_strategy(q, "rrf", top_k, **kw)
+                    assert got == exp, (q, top_k, kw)
+    finally:
+        em.model.encode = real_encode
+        scorer.hybrid_tail = real_tail
+    assert calls["mmr_in_kernel"] >= 10, calls         # candidate sets of one-chunk documents only: MMR in the kernel
+    assert calls["encode"] >= 10, calls                # others (multi-chunk documents among them) were re-encoded
+    # a cross-encoder keeps fusion + cut in the kernel and everything behind it on the host
+    class FakeCE:
+        def predict(self, pairs):
+            return [float(len(p[1]) % 7) for p in pairs]
+    a = SearchEngine(store, em, cross_encoder=FakeCE()).search_with_strategy(queries[0], "rrf", 5, use_mmr=True)
+    b = SearchEngine(store, em, cross_encoder=FakeCE())
+    b._rrf_tail = lambda *x, **k: None
+    assert a == b.search_with_strategy(queries[0], "rrf", 5, use_mmr=True)
