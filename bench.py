@@ -561,7 +561,8 @@ def prefilter_leg(env, main_run, main_ms, args):
 def c5_leg(n_queries=40):
     """BASELINE config 5: strategy=rrf + MMR over 1M synthetic documents, whole query through the
     host classes (benchmarks/hybrid_workload.py); parity-checked after the timed loop."""
-    from benchmarks.hybrid_workload import HybridWorkload, STAGES
+    from benchmarks.hybrid_workload import (HybridWorkload, STAGES, cpu_baseline as c5_cpu, make_search_engine,
+                                            time_search_engine)
     wl = HybridWorkload(1_000_000, 200_000, 384, n_queries, 10, log)
     for qi in range(10):     # first calls size workspaces and set kernel attributes
         wl.query(qi % n_queries)
@@ -570,7 +571,18 @@ def c5_leg(n_queries=40):
     results = [wl.query(qi, tsum, sb, keep_emb=qi < 3) for qi in range(n_queries)]
     checked = wl.check([0, 1, 2], results[:3])
     nq = float(n_queries)
-    return {"workload": "strategy=rrf + MMR, 1M docs, vocab 200k, %d postings, dense 1M x 384 fp32, top_k=10" % wl.nnz,
+    extra = {}
+    try:      # the same queries through the product class (rag_system_amd.SearchEngine on a VectorStorage)
+        eng, _store, qtexts = make_search_engine(wl, log)
+        extra["through_search_engine"] = time_search_engine(wl, eng, qtexts, n_queries, 10, {qi: results[qi] for qi in range(3)})
+        del eng, _store
+    except Exception as e:
+        extra["through_search_engine"] = {"error": repr(e)}
+    try:
+        extra["cpu_baseline"] = c5_cpu(wl, 40_000, 4, log)
+    except Exception as e:
+        extra["cpu_baseline"] = {"error": repr(e)}
+    return {**extra, "workload": "strategy=rrf + MMR, 1M docs, vocab 200k, %d postings, dense 1M x 384 fp32, top_k=10" % wl.nnz,
             "value": nq / tsum["total"], "unit": "QPS", "ms_per_query": tsum["total"] / nq * 1e3,
             "stage_ms": {s: tsum[s] / nq * 1e3 for s in STAGES},
             "sparse_roofline": {s: {"bound": "hbm", "achieved": sb[s] / tsum[s] / 1e9, "peak": HBM_PEAK_GBS,

@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
     ap.add_argument("--cpu-queries", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--search-engine", action="store_true",
+                    help="also time the queries through rag_system_amd.SearchEngine on a VectorStorage over the same indices")
+    ap.add_argument("--no-tail", action="store_true", help="the three-call route instead of rag_hybrid_rrf_mmr")
     ap.add_argument("--profile-loop", action="store_true", help="cProfile the timed query loop (stderr)")
     args = ap.parse_args()
     n, V, d, top_k = args.docs, args.vocab, args.dim, args.top_k
@@ -66,7 +69,7 @@ def main():
     results = []
     log("warm-up")
     for qi in range(min(3, args.queries)):
-        wl.query(qi)
+        wl.query(qi, tail=not args.no_tail)
     log("timing %d queries" % args.queries)
     prof = None
     if args.profile_loop:
@@ -74,7 +77,7 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     for qi in range(args.queries):
-        results.append(wl.query(qi, tsum, sparse_bytes, keep_emb=qi < 8))
+        results.append(wl.query(qi, tsum, sparse_bytes, keep_emb=qi < 8, tail=not args.no_tail))
     if prof is not None:
         import io
         import pstats
@@ -89,7 +92,6 @@ def main():
     ncheck = min(8, args.queries)
     log("parity check against oracle/ on %d queries" % ncheck)
     checked = wl.check(list(range(ncheck)), results[:ncheck])
-    indptr, terms, queries, bm, Qd = wl.indptr, wl.terms, wl.queries, wl.bm, wl.Qd
 
     out = {
         "metric": "QPS, strategy=rrf (dense + BM25Okapi + TF-IDF + RRF + MMR) over %d synthetic documents" % n,
@@ -109,47 +111,15 @@ def main():
                    "ranks": "exact", "dense": "ids exact", "rrf": "identical to RRF over the full rankings",
                    "mmr": "identical order"},
     }
+    if args.search_engine:
+        from benchmarks.hybrid_workload import make_search_engine, time_search_engine
+        eng, _store, qtexts = make_search_engine(wl, log)
+        out["through_search_engine"] = time_search_engine(wl, eng, qtexts, args.queries, top_k,
+                                                          {qi: results[qi] for qi in range(ncheck)})
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_leg(args, indptr, terms, queries, bm, Qd, top_k)
+        from benchmarks.hybrid_workload import cpu_baseline
+        out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_docs, args.cpu_queries, log)
     print(json.dumps(out), flush=True)
-
-
-def cpu_leg(args, indptr, terms, queries, bm, Qd, top_k):
-    """The reference's own per-query work (rank_bm25 dict loop + Python sorts + sklearn cosine
-    + faiss-style flat scan) restated on the first `cpu_sample_docs` documents, one core."""
-    from oracle import dense as od
-    from oracle import sparse as osp
-    from sklearn.metrics.pairwise import cosine_similarity
-    m = min(args.cpu_sample_docs, args.docs)
-    log("CPU leg: restatement on the first %d documents" % m)
-    corpus = [terms[indptr[i]:indptr[i + 1]].tolist() for i in range(m)]
-    ref = osp.BM25OkapiRef(corpus, k1=1.0, b=0.65)
-    M, _ = None, None
-    X = od.synth_rows(1234, 0, m, args.dim)
-    from scipy.sparse import csr_matrix
-    from sklearn.feature_extraction.text import TfidfTransformer
-    lens = np.diff(indptr[:m + 1])
-    counts = csr_matrix((np.ones(int(lens.sum())), terms[:int(indptr[m])], indptr[:m + 1]),
-                        shape=(m, args.vocab))
-    counts.sum_duplicates()
-    tr = TfidfTransformer()
-    Mtf = tr.fit_transform(counts)
-    t0 = time.perf_counter()
-    nq = min(args.cpu_queries, len(queries))
-    for qi in range(nq):
-        raw = queries[qi]
-        s = ref.get_scores(raw)
-        sorted(range(len(s)), key=lambda i: s[i], reverse=True)[:3 * top_k]
-        qv = tr.transform(csr_matrix((np.ones(len(raw)), (np.zeros(len(raw), int), raw)), shape=(1, args.vocab)))
-        sc = cosine_similarity(qv, Mtf)[0]
-        sorted(((i, float(sc[i])) for i in range(m)), key=lambda x: x[1], reverse=True)
-        od.cpu_baseline_search(X, Qd[qi:qi + 1], 9 * top_k, 1)
-    el = time.perf_counter() - t0
-    scale = m / float(args.docs)
-    return {"value": nq / el * scale, "unit": "QPS", "cores": 1, "kind": "port",
-            "sample": "%d queries over the first %d of %d documents (%.1f s): rank_bm25-style dict loop + Python "
-                      "sorts over all documents + sklearn cosine + flat fp32 scan; QPS scaled by the document "
-                      "ratio (every term is linear in the document count)" % (nq, m, args.docs, el)}
 
 
 if __name__ == "__main__":

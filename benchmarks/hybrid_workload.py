@@ -224,3 +224,168 @@ class HybridWorkload:
             sel = ofu.mmr_selection(emb, self.Qd[qi], [120] * len(ids), 0.5, top_k, None)
             assert [ids[i] for i in sel] == r["mmr"], "MMR order differs (query %d)" % qi
         return len(qis)
+
+
+# --------------------------------------------------------------------------------------------- product class
+
+def token_texts(indptr, terms):
+    """Document texts for integer-token corpora: token 123 -> the word "t000123", words joined by blanks (what a
+    chunker would hand to add_vector); vectorised, one ASCII buffer for the whole corpus."""
+    n_tok = len(terms)
+    buf = np.empty((n_tok, 8), dtype=np.uint8)
+    buf[:, 0] = ord("t")
+    buf[:, 7] = ord(" ")
+    v = terms.astype(np.int32)
+    for j in range(6, 0, -1):
+        buf[:, j] = (48 + v % 10).astype(np.uint8)
+        v = v // 10
+    flat = buf.reshape(-1).tobytes()
+    return [flat[8 * int(a):8 * int(b) - 1].decode("ascii") for a, b in zip(indptr[:-1], indptr[1:])]
+
+
+class _TokenVectorizer:
+    """Stand-in for the fitted sklearn TfidfVectorizer of such a store: transform([text]) -> the 1 x n_terms CSR
+    row of tf * idf weights (columns = term ids).  The row is left un-normalised (cosine_similarity normalises the
+    query anyway, search_engine.py:285), which keeps the weights identical to HybridWorkload.query's."""
+
+    def __init__(self, vocab, idf, n_terms):
+        self.vocab, self.idf, self.n_terms = vocab, idf, n_terms
+
+    def transform(self, texts):
+        from scipy.sparse import csr_matrix
+        ids = [self.vocab[t] for t in texts[0].lower().split() if t in self.vocab]
+        uq, cnt = np.unique(np.asarray(ids, dtype=np.int64), return_counts=True)
+        return csr_matrix((cnt * self.idf[uq], uq.astype(np.int32), np.array([0, len(uq)], dtype=np.int32)),
+                          shape=(1, self.n_terms))
+
+
+class _LookupEmbeddingManager:
+    """embed_query by table: the synthetic queries' dense vectors are given (producing embeddings is outside the
+    hot path, SURVEY 2 #3)."""
+    model_name, chunk_size, overlap = "synthetic", 100, 20
+
+    def __init__(self, table):
+        self._table = table
+
+        class _NoModel:
+            def encode(self, texts, *a, **k):
+                raise RuntimeError("the synthetic store has no text encoder (MMR runs on the stored rows)")
+        self.model = _NoModel()
+
+    def embed_query(self, query):
+        return self._table[query]
+
+
+def make_search_engine(wl, log=None):
+    """rag_system_amd.VectorStorage + SearchEngine over the SAME indices as `wl` (one chunk per document, texts of
+    integer-token words), so that search_with_strategy("rrf", ...) can be timed and compared with wl.query()."""
+    import copy
+    from rag_system_amd.search_engine import SearchEngine
+    from rag_system_amd.vector_storage import VectorStorage
+    log = log or (lambda m: None)
+    n = wl.n
+    log("product store: %d document texts" % n)
+    texts = token_texts(wl.indptr, wl.terms)
+    ids = ["doc%07d" % i for i in range(n)]
+    store = VectorStorage(wl.d, embedder="synthetic")
+    store.index = wl.index
+    store.doc_ids = ids
+    store.chunks_data = [{"doc_id": d, "chunk": t, "source": None} for d, t in zip(ids, texts)]
+    store.documents = {d: {"chunks": [{"chunk": t, "source": None}]} for d, t in zip(ids, texts)}
+    bm = copy.copy(wl.bm)                       # the same postings handle, vocabulary keyed by the words of the texts
+    bm._vocab = {"t%06d" % w: t for w, t in wl.bm._vocab.items()}
+    store.bm25, store.bm25_doc_ids, store.bm25_indexed_count = bm, store.chunks_data, n
+    vec = _TokenVectorizer(bm._vocab, wl.tfidf_idf, wl.n_terms)
+    store.tfidf_index, store.tfidf_vectorizer, store.tfidf_doc_ids = wl.M, vec, ids
+    wl.ts.vectorizer = vec
+    store._tfidf_scorer, store._tfidf_scorer_key = wl.ts, (id(vec), id(wl.M))
+    qtexts = [" ".join("t%06d" % t for t in raw) for raw in wl.queries]
+    em = _LookupEmbeddingManager({t: wl.Qd[i] for i, t in enumerate(qtexts)})
+    return SearchEngine(store, em), store, qtexts
+
+
+def time_search_engine(wl, eng, qtexts, n_queries, top_k, expect=None):
+    """search_with_strategy(q, "rrf", top_k, use_mmr=True, mmr_reuse_index_vectors=True) per query: wall clock,
+    then a second pass with per-stage timers around the engine's own methods.  expect[qi] = wl.query(qi): the
+    returned documents and scores must be the workload's (same indices, same kernels)."""
+    kw = dict(strategy="rrf", top_k=top_k, use_mmr=True, mmr_lambda=0.5, mmr_reuse_index_vectors=True)
+    for qi in range(min(5, n_queries)):
+        eng.search_with_strategy(qtexts[qi], **kw)
+    t0 = time.perf_counter()
+    res = [eng.search_with_strategy(qtexts[qi], **kw) for qi in range(n_queries)]
+    total = time.perf_counter() - t0
+    if expect is not None:
+        for qi, r in expect.items():
+            got = [int(x["doc_id"][3:]) for x in res[qi]]
+            assert got == r["mmr"], "SearchEngine returns other documents than the workload (query %d)" % qi
+            sc = dict(r["fused"])
+            assert all(x["score"] == sc[int(x["doc_id"][3:])] for x in res[qi]), "fused scores differ (query %d)" % qi
+    # per-stage pass (timers add a little; reported beside, not inside, the wall clock above)
+    acc = {}
+
+    def timed(obj, name, key):
+        fn = getattr(obj, name)
+
+        def wrapper(*a, **k):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                acc[key] = acc.get(key, 0.0) + time.perf_counter() - t
+        setattr(obj, name, wrapper)
+        return fn
+    saved = [(eng, "_search_faiss_begin", timed(eng, "_search_faiss_begin", "embed + dense begin")),
+             (eng, "_tfidf_begin", timed(eng, "_tfidf_begin", "tfidf vectorise + begin")),
+             (eng, "search_bm25", timed(eng, "search_bm25", "bm25 (tokenise, call, hit dicts)")),
+             (eng, "_search_faiss_end", timed(eng, "_search_faiss_end", "dense end (wait, hit dicts, group by doc)")),
+             (eng, "_rrf_tail", timed(eng, "_rrf_tail", "tail (rows, one call, result dicts)"))]
+    t1 = time.perf_counter()
+    for qi in range(n_queries):
+        eng.search_with_strategy(qtexts[qi], **kw)
+    total2 = time.perf_counter() - t1
+    for obj, name, fn in saved:
+        setattr(obj, name, fn)
+    stage_ms = {k: v / n_queries * 1e3 for k, v in acc.items()}
+    stage_ms["other (dispatch, sort, knee / threshold)"] = (total2 - sum(acc.values())) / n_queries * 1e3
+    return {"value": n_queries / total, "unit": "QPS", "ms_per_query": total / n_queries * 1e3, "stage_ms": stage_ms,
+            "call": "SearchEngine.search_with_strategy(q, 'rrf', %d, use_mmr=True, mmr_reuse_index_vectors=True) on a "
+                    "VectorStorage over the same indices (1 chunk per document, texts of integer-token words; "
+                    "query vectors by lookup, a light stand-in for the fitted TfidfVectorizer)" % top_k}
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+
+def cpu_baseline(wl, sample_docs=50_000, n_queries=5, log=None):
+    """The reference's own per-query work (rank_bm25 dict loop + Python sorts over all documents + sklearn cosine
+    + faiss-style flat scan) restated on the first `sample_docs` documents, one core (oracle/: baseline role)."""
+    from oracle import dense as od
+    from oracle import sparse as osp
+    from scipy.sparse import csr_matrix
+    from sklearn.feature_extraction.text import TfidfTransformer
+    from sklearn.metrics.pairwise import cosine_similarity
+    (log or (lambda m: None))("CPU leg: restatement on the first %d documents" % sample_docs)
+    indptr, terms, top_k = wl.indptr, wl.terms, wl.top_k
+    m = min(sample_docs, wl.n)
+    corpus = [terms[indptr[i]:indptr[i + 1]].tolist() for i in range(m)]
+    ref = osp.BM25OkapiRef(corpus, k1=1.0, b=0.65)
+    X = od.synth_rows(1234, 0, m, wl.d)
+    lens = np.diff(indptr[:m + 1])
+    counts = csr_matrix((np.ones(int(lens.sum())), terms[:int(indptr[m])], indptr[:m + 1]), shape=(m, wl.V))
+    counts.sum_duplicates()
+    tr = TfidfTransformer()
+    Mtf = tr.fit_transform(counts)
+    nq = min(n_queries, len(wl.queries))
+    t0 = time.perf_counter()
+    for qi in range(nq):
+        raw = wl.queries[qi]
+        s = ref.get_scores(raw)
+        sorted(range(len(s)), key=lambda i: s[i], reverse=True)[:3 * top_k]
+        qv = tr.transform(csr_matrix((np.ones(len(raw)), (np.zeros(len(raw), int), raw)), shape=(1, wl.V)))
+        sc = cosine_similarity(qv, Mtf)[0]
+        sorted(((i, float(sc[i])) for i in range(m)), key=lambda x: x[1], reverse=True)
+        od.cpu_baseline_search(X, wl.Qd[qi:qi + 1], 9 * top_k, 1)
+    el = time.perf_counter() - t0
+    return {"value": nq / el * (m / float(wl.n)), "unit": "QPS", "cores": 1, "kind": "port",
+            "sample": "%d queries over the first %d of %d documents (%.1f s): rank_bm25-style dict loop + Python "
+                      "sorts over all documents + sklearn cosine + flat fp32 scan; QPS scaled by the document "
+                      "ratio (every term is linear in the document count)" % (nq, m, wl.n, el)}

@@ -10,6 +10,8 @@
 #include <cfloat>
 #include <algorithm>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -472,61 +474,107 @@ struct HybOut {
     double fscore[HYB_MAX_TOPK];
     int order[HYB_MAX_TOPK];       // MMR: indices into the kept entries, in selection order
 };
+// (the arguments come through pinned memory into LDS: as a by-value kernel argument the struct's arrays, indexed
+// per lane, were spilled to scratch by every one of the 1024 lanes)
 __global__ __launch_bounds__(CAND_THREADS) void hybrid_tail_kernel(
-    const HybArgs a, const long long* __restrict__ head_I, const int* __restrict__ overflow_flag,
+    const HybArgs* __restrict__ ap, const long long* __restrict__ head_I, const int* __restrict__ overflow_flag,
     const unsigned long long* __restrict__ ranks, const long long* __restrict__ doc_row,
     const long long* __restrict__ doc_bytes, const float* __restrict__ q, const void* __restrict__ arena,
     HybOut* __restrict__ out) {
     constexpr int NF = HYB_MAX_A + HYB_MAX_HEAD;
+    constexpr int NW = CAND_THREADS / 64;
+    extern __shared__ __align__(16) float hyb_dyn[];  // the MMR stage's LDS image; [0, d) = the query (mmr_body)
     __shared__ double s_score[NF];
+    __shared__ double s_inv[HYB_MAX_HEAD];     // 1 / (k + rank) of the list positions
     __shared__ long long s_row[NF];
+    __shared__ unsigned long long s_rank[HYB_MAX_A];
     __shared__ unsigned char s_live[NF];
     __shared__ int s_topf[HYB_MAX_TOPK];       // fused position -> entry
     __shared__ long long s_mrow[HYB_MAX_TOPK], s_mbytes[HYB_MAX_TOPK];
     __shared__ int s_nkept, s_mmr_ok, s_status;
-    const int tid = threadIdx.x;
-    const int nF = a.nA + a.n_head;
+    __shared__ int s_kept[HYB_MAX_TOPK];
+    __shared__ HybArgs a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // Everything that comes from pinned host memory or waits in HBM is requested at once: the arguments, the
+    // overflow flag and the head of the begun selection, the candidates' ranks, and the query for the MMR stage
+    // (one trip over the host link costs ~2.6 us here; the phases below are latency-bound LDS work, laid out so
+    // that a wave works on one entry at a time with ballots instead of every lane walking a list alone: the
+    // lane-serial version of this kernel spent 24 us in the two loops)
+    static_assert(sizeof(HybArgs) % 4 == 0, "copied word by word");
+    for (int w = tid; w < (int)(sizeof(HybArgs) / 4); w += CAND_THREADS)
+        reinterpret_cast<int*>(&a)[w] = reinterpret_cast<const int*>(ap)[w];
     if (tid == 0) s_status = *overflow_flag != 0 ? 1 : 0;
-    for (int j = tid; j < a.n_head; j += CAND_THREADS) s_row[a.nA + j] = head_I[j];
+    long long head_v = -1;     // (n_head <= 320 < CAND_THREADS: one entry per lane)
+    if (tid < HYB_MAX_HEAD) head_v = head_I[tid];
+    if (tid < HYB_MAX_A) s_rank[tid] = ranks[tid];   // (the buffer holds 1024 entries; those beyond the query are stale, unused)
+    __syncthreads();
+    const int nF = a.nA + a.n_head;
+    if (a.do_mmr)
+        for (int c = tid; c < a.d; c += CAND_THREADS) hyb_dyn[c] = q[c];
+    if (tid < a.n_head) s_row[a.nA + tid] = head_v;
     for (int i = tid; i < a.nA; i += CAND_THREADS) s_row[i] = a.a_row[i];
+    if (tid < HYB_MAX_HEAD) s_inv[tid] = 1.0 / (a.k_const + (double)tid);
     __syncthreads();
     if (s_status) {
         if (tid == 0) out->status = 1;
         return;
     }
-    // scores: a candidate's terms in Python's order (dense ranking, BM25 ranking entry by entry, TF-IDF); a head
-    // document that is no candidate has its TF-IDF term only
-    for (int f = tid; f < nF; f += CAND_THREADS) {
+    // scores: a candidate's terms in Python's order (dense ranking, BM25 ranking entry by entry, TF-IDF)
+    for (int f = wid; f < a.nA; f += NW) {
         double s = 0.0;
-        bool live = true;
-        if (f < a.nA) {
-            for (int j = 0; j < a.n_dense; ++j)
-                if (a.dense_a[j] == f) s = s + 1.0 / (a.k_const + (double)j);
-            for (int j = 0; j < a.n_bm25; ++j)
-                if (a.bm25_a[j] == f) s = s + 1.0 / (a.k_const + (double)j);
-            if (a.a_rk[f] >= 0) s = s + 1.0 / (a.k_const + (double)ranks[a.a_rk[f]]);
-        } else {
-            const long long r = s_row[f];
-            for (int i = 0; i < a.nA; ++i) live = live && s_row[i] != r;
-            s = 0.0 + 1.0 / (a.k_const + (double)(f - a.nA));
+        for (int base = 0; base < a.n_dense; base += 64) {
+            const int jj = base + lane;
+            unsigned long long m = __ballot(jj < a.n_dense && a.dense_a[jj] == f);
+            while (m) {
+                s = s + s_inv[base + __builtin_ctzll(m)];
+                m &= m - 1;
+            }
         }
-        s_score[f] = s;
-        s_live[f] = live ? 1 : 0;
+        for (int base = 0; base < a.n_bm25; base += 64) {
+            const int jj = base + lane;
+            unsigned long long m = __ballot(jj < a.n_bm25 && a.bm25_a[jj] == f);
+            while (m) {
+                s = s + s_inv[base + __builtin_ctzll(m)];
+                m &= m - 1;
+            }
+        }
+        if (a.a_rk[f] >= 0) s = s + 1.0 / (a.k_const + (double)s_rank[a.a_rk[f]]);
+        if (lane == 0) {
+            s_score[f] = s;
+            s_live[f] = 1;
+        }
+    }
+    // a head document that is no candidate has its TF-IDF term only; one that is, is already counted
+    for (int h = wid; h < a.n_head; h += NW) {
+        const long long r = s_row[a.nA + h];
+        bool found = false;
+        for (int base = 0; base < a.nA; base += 64) {
+            const int i2 = base + lane;
+            found = found || __any(i2 < a.nA && s_row[i2] == r);
+        }
+        if (lane == 0) {
+            s_score[a.nA + h] = 0.0 + s_inv[h];
+            s_live[a.nA + h] = found ? 0 : 1;
+        }
     }
     __syncthreads();
     // stable descending order by counting (ties: dictionary insertion order = entry number); cut to top_k
-    int nlive = 0;
-    for (int f = 0; f < nF; ++f) nlive += s_live[f];   // (block-uniform; nF <= 576)
+    const int nlive = __syncthreads_count(tid < nF && s_live[tid]);   // (nF <= 576 < CAND_THREADS)
     const int nfused = nlive < a.top_k ? nlive : a.top_k;
-    for (int f = tid; f < nF; f += CAND_THREADS) {
+    for (int f = wid; f < nF; f += NW) {
         if (!s_live[f]) continue;
         const double s = s_score[f];
         int pos = 0;
-        for (int g = 0; g < nF; ++g) {
-            const double t = s_score[g];
-            pos += (s_live[g] && (t > s || (t == s && g < f))) ? 1 : 0;
+        for (int base = 0; base < nF; base += 64) {
+            const int g = base + lane;
+            bool ahead = false;
+            if (g < nF && s_live[g]) {
+                const double t = s_score[g];
+                ahead = t > s || (t == s && g < f);
+            }
+            pos += __popcll(__ballot(ahead));
         }
-        if (pos < a.top_k) s_topf[pos] = f;
+        if (lane == 0 && pos < a.top_k) s_topf[pos] = f;
     }
     __syncthreads();
     if (tid < nfused) {
@@ -537,7 +585,6 @@ __global__ __launch_bounds__(CAND_THREADS) void hybrid_tail_kernel(
     }
     if (tid == 0) {
         // search_with_strategy :121-129: (already sorted) knee cutoff with strict >, then threshold with >=
-        int kept[HYB_MAX_TOPK];
         int nk = 0;
         double cutoff = 0.0;
         bool knee = a.use_knee != 0 && nfused > 0;
@@ -560,31 +607,37 @@ __global__ __launch_bounds__(CAND_THREADS) void hybrid_tail_kernel(
             const double s = s_score[s_topf[i]];
             if (knee && !(s > cutoff)) continue;
             if (!(s >= a.threshold)) continue;
-            kept[nk++] = i;
-        }
-        int ok = a.do_mmr != 0 && nk > 0 && doc_row != nullptr && doc_bytes != nullptr;
-        for (int i = 0; i < nk && ok; ++i) {
-            const long long r = s_row[s_topf[kept[i]]];
-            if (r < 0) {
-                ok = 0;
-                break;
-            }
-            const long long ar = doc_row[r];
-            if (ar < 0 || ar >= a.n_arena) ok = 0;
-            s_mrow[i] = ar;
-            s_mbytes[i] = doc_bytes[r];
+            s_kept[nk++] = i;
         }
         s_nkept = nk;
-        s_mmr_ok = ok;
+        s_mmr_ok = a.do_mmr != 0 && nk > 0 && doc_row != nullptr && doc_bytes != nullptr;
         out->status = 0;
         out->n_fused = nfused;
         out->n_kept = nk;
+    }
+    __syncthreads();
+    // the embeddings' rows and the byte lengths of the kept documents: one lane each, all loads in flight at once
+    bool bad = false;
+    if (s_mmr_ok && tid < s_nkept) {
+        const long long r = s_row[s_topf[s_kept[tid]]];
+        long long ar = -1, nb = 0;
+        if (r >= 0) {
+            ar = doc_row[r];
+            nb = doc_bytes[r];
+        }
+        bad = ar < 0 || ar >= a.n_arena;
+        s_mrow[tid] = bad ? 0 : ar;
+        s_mbytes[tid] = nb;
+    }
+    const int nbad = __syncthreads_count(bad);
+    if (tid == 0) {
+        const int ok = s_mmr_ok && nbad == 0;
         out->mmr_done = ok;
         if (!ok) out->n_sel = 0;
     }
-    __syncthreads();
-    if (!s_mmr_ok) return;
-    mmr_body<true, true>(nullptr, q, s_nkept, a.d, a.lambda, a.top_k, s_mbytes, a.max_bytes, nullptr, nullptr, nullptr,
+    if (!s_mmr_ok || nbad != 0) return;
+    // (the query is in the LDS image already: mmr_body copies it onto itself)
+    mmr_body<true, true>(nullptr, hyb_dyn, s_nkept, a.d, a.lambda, a.top_k, s_mbytes, a.max_bytes, nullptr, nullptr, nullptr,
                          out->order, &out->n_sel, s_mrow, arena, a.ld, a.bf16);
 }
 
@@ -873,22 +926,28 @@ int rag_hybrid_rrf_mmr(rag_csc_t* tfidf, rag_flat_t* flat, int n_dense, const in
         CandWs& ws = cand_ws();
         std::lock_guard<std::mutex> lk(ws.mu);
         const size_t q_b = al8((size_t)std::max(c.a.d, 1) * sizeof(float));
-        int rc = ws.reserve(64, q_b + sizeof(HybOut));
+        int rc = ws.reserve(64, q_b + al8(sizeof(HybOut)) + sizeof(HybArgs));
         if (rc) return rc;
         float* hq = reinterpret_cast<float*>(ws.pin);
         HybOut* ho = reinterpret_cast<HybOut*>(ws.pin + q_b);
+        HybArgs* ha = reinterpret_cast<HybArgs*>(ws.pin + q_b + al8(sizeof(HybOut)));
         if (c.a.do_mmr) std::memcpy(hq, c.q, (size_t)c.a.d * sizeof(float));
         ho->status = -1;
-        const size_t smem = c.a.do_mmr ? ((size_t)c.a.top_k * c.a.d + c.a.d) * sizeof(float) : 0;
-        if (smem > 0) {
-            static bool attr_done = false;  // under ws.mu
-            if (!attr_done) {
-                RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_tail_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MMR_LDS_BYTES));
-                attr_done = true;
-            }
+        size_t smem = c.a.do_mmr ? ((size_t)c.a.top_k * c.a.d + c.a.d) * sizeof(float) : 0;
+        static size_t dyn_max = 0;  // under ws.mu: what the CU's 160 KiB of LDS leave beside the kernel's static arrays
+        if (smem > 0 && dyn_max == 0) {
+            hipFuncAttributes fa;
+            RAG_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(hybrid_tail_kernel)));
+            dyn_max = std::min<size_t>(MMR_LDS_BYTES, ((size_t)160 << 10) - fa.sharedSizeBytes) & ~(size_t)255;
+            RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_tail_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
         }
-        hybrid_tail_kernel<<<1, CAND_THREADS, smem, v.st>>>(c.a, v.head_I, v.overflow_flag, v.ranks, v.doc_row, v.doc_bytes,
+        if (smem > dyn_max) {       // rows too long for the LDS image: fusion only, MMR left to the caller
+            c.a.do_mmr = 0;
+            smem = 0;
+        }
+        *ha = c.a;
+        hybrid_tail_kernel<<<1, CAND_THREADS, smem, v.st>>>(ha, v.head_I, v.overflow_flag, v.ranks, v.doc_row, v.doc_bytes,
                                                            hq, arena, ho);
         RAG_HIP(hipGetLastError());
         RAG_HIP(hipStreamSynchronize(v.st));

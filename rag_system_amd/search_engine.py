@@ -141,6 +141,14 @@ class SearchEngine:
             r["score"] = float(r["score"])
         return hits
 
+    def _dense_pairs_end(self, token):
+        """[(doc_id, score)] of a begun dense search for stores that offer it (search_end(ids_only=True)), else
+        None (nothing was collected yet)."""
+        vs = self.vector_storage
+        if not hasattr(vs, "hybrid_doc_tables"):     # not rag_system_amd's VectorStorage (test fakes): the dict route
+            return None
+        return vs.search_end(token.tok, ids_only=True)
+
     def _dense_abort(self, token):
         """A stage between the two halves raised: collect the begun dense search (its result is dropped) so
         that the index accepts the next one."""
@@ -171,6 +179,16 @@ class SearchEngine:
         if pending is None:
             return []
         token, query, top_k, retrieval_mode = pending
+        if retrieval_mode == "document" and not want_text and not self.cross_encoder:
+            pairs = self._dense_pairs_end(token)
+            if pairs is not None:       # per-document maximum in first-hit order (:148-155), no dictionaries per hit
+                best = {}
+                for d, sc in pairs:
+                    if d not in best or sc > best[d]:
+                        best[d] = sc
+                results = [{"doc_id": d, "score": sc} for d, sc in best.items()]
+                results.sort(key=lambda x: x["score"], reverse=True)
+                return results[:top_k]
         hits = self._dense_chunks_end(token)
         if retrieval_mode == "document":
             groups = self._group_dense_by_doc(hits)

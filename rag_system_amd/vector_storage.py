@@ -124,11 +124,16 @@ class VectorStorage:
         q = np.array(query_vector, dtype="float32").reshape(1, -1)
         return ("pending", self.index.search_begin(q, top_k))
 
-    def search_end(self, token):
+    def search_end(self, token, ids_only=False):
+        """ids_only=True (not in the reference; the fusion strategies, which read nothing but doc_id and score of
+        the dense hits): [(doc_id, score)] in hit order instead of the result dictionaries."""
         kind, val = token
         if kind == "done":
-            return val
+            return [(r["doc_id"], float(r["score"])) for r in val] if ids_only else val
         distances, indices = self.index.search_end(val)
+        if ids_only:
+            doc_ids = self.doc_ids          # aligned with chunks_data; -1 (k > ntotal) is the last chunk there too
+            return [(doc_ids[i], s) for s, i in zip(distances[0].tolist(), indices[0].tolist())]
         hits = []
         for dist, idx in zip(distances[0], indices[0]):
             cdata = self.chunks_data[idx]   # idx == -1 (k > ntotal) is the last chunk, as in the reference
