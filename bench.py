@@ -112,6 +112,48 @@ def cpu_baseline(args, Q):
     return out
 
 
+def cpu_baseline_batch(args, Q, nq=1024, sample_rows=400_000, budget_s=8.0):
+    """The batch half of the metric on the host cores: numpy `Q @ X.T` (the BLAS sgemm faiss-cpu uses for
+    nq >= 20, all cores) + a per-block argpartition top-k, on a bounded sample of the rows, scaled by the row
+    ratio.  A restatement, not faiss."""
+    from oracle import dense as od
+    import numpy as np
+    rows = min(sample_rows, args.rows)
+    X = od.synth_rows(args.seed, 0, rows, args.dim)
+    Q = np.ascontiguousarray(Q[:nq])
+    k = args.k
+    blk = 50_000
+
+    def once():
+        best_s = np.full((len(Q), k), -np.inf, dtype=np.float32)
+        best_i = np.zeros((len(Q), k), dtype=np.int64)
+        for b0 in range(0, rows, blk):
+            S = Q @ X[b0:b0 + blk].T
+            idx = np.argpartition(S, -k, axis=1)[:, -k:]
+            cs = np.concatenate([best_s, np.take_along_axis(S, idx, axis=1)], axis=1)
+            ci = np.concatenate([best_i, idx + b0], axis=1)
+            keep = np.argpartition(cs, -k, axis=1)[:, -k:]
+            best_s, best_i = np.take_along_axis(cs, keep, axis=1), np.take_along_axis(ci, keep, axis=1)
+        return best_s, best_i
+    once()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 20:
+        once()
+        reps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    return {"value": len(Q) * reps / el * rows / float(args.rows), "unit": "QPS", "cores": cores, "kind": "port",
+            "sample": "nq=%d top-%d over the first %d of %d rows, numpy sgemm + argpartition in blocks of %d rows (%d "
+                      "reps, %.1f s, %.0f GFLOP/s); QPS scaled by the row ratio; restatement, not faiss"
+                      % (len(Q), k, rows, args.rows, blk, reps, el, 2.0 * len(Q) * rows * args.dim * reps / el / 1e9)}
+
+
 def kernel_name(nq, k, n_local, bf, d=0):
     """Which kernel makes the timed pass (the engine's dispatch, csrc/flat.hip search_device; the
     rocprofv3 summaries under profiles/ show the same names)."""
@@ -511,6 +553,13 @@ def main():
             qg = faiss.IndexFlatIP(d)
             qg._b.add_synthetic(max(nq, 1), 4321, 0)
             out["cpu_baseline"] = cpu_baseline(args, qg.reconstruct_n(0, max(nq, 1)))
+            if out.get("batch1024") is not None:
+                try:
+                    qb = faiss.IndexFlatIP(d)
+                    qb._b.add_synthetic(1024, 4321, 0)
+                    out["batch1024"]["cpu_baseline"] = cpu_baseline_batch(args, qb.reconstruct_n(0, 1024))
+                except Exception as e:
+                    out["batch1024"]["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
     if world > 1:

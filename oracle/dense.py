@@ -146,6 +146,10 @@ def check_topk(D, I, D_ref64, I_ref, rtol=1e-5, atol=1e-6, exact_scores=None):
     bad = (~pad) & (np.abs(D - D_ref64) > tol)
     assert not bad.any(), "scores differ beyond tolerance at %s: %s vs %s" % (
         np.argwhere(bad)[:5].tolist(), D[bad][:5], D_ref64[bad][:5])
+    # every returned id at most once per query (a repeated id could otherwise pass as a near-tie of two ranks)
+    for qi in range(I.shape[0]):
+        vals, counts = np.unique(I[qi][~pad[qi]], return_counts=True)
+        assert (counts == 1).all(), "query %d: ids returned more than once: %s" % (qi, vals[counts > 1][:6].tolist())
     diff = (~pad) & (I != I_ref)
     ndiff = int(diff.sum())
     if ndiff:

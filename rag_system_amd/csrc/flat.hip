@@ -1179,7 +1179,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     int rc = RAG_OK;
     // 65..192 queries on a large shard: two or three passes of the 16x16 register-fed kernel
     // (flat_wide.hip, <= 64 queries per pass) beat the LDS tile kernel, whose 128-query block shapes
-    // are half empty there (10M x 384, benchmarks/run_mid_nq.sh: 65 / 96 / 128 / 192 queries
+    // are half empty there (10M x 384, benchmarks/ab/run_mid_nq.sh: 65 / 96 / 128 / 192 queries
     // 8.9 / 9.0 / 9.4 / 16.2 ms on the tile kernel against 3.65-4.5 ms per pass).
     // fp32 rows only: bfloat16 passes are bound by re-reading the rows, and the tile kernel needs
     // one pass (10M x 768 bf16, 65 / 128 queries: 4.2 / 4.4 ms against 5.2 / 5.8 ms in chunks).
@@ -1223,7 +1223,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
     // One or two queries, k <= 128: the stream kernel (flat_stream.hip) where it applies -- it reads
     // the rows a little faster than the scan kernel below (10M x 384 fp32, nq = 1: 2.171 against
     // 2.19-2.26 ms per pass; 10M x 768 bf16: 2.164 against 2.28; k = 100 through filter mode 2.35
-    // against 2.41-2.46 ms per step; benchmarks/run_nq1_stream.sh).  An explicit "mfma_min_nq"
+    // against 2.41-2.46 ms per step; benchmarks/ab/run_nq1_stream.sh).  An explicit "mfma_min_nq"
     // keeps such batches on the scan kernel.
     StreamPlan small_probe;
     const bool small_stream = opt.mfma_min_nq <= 0 && nq < mfma_min_nq && k <= 128 &&
@@ -1322,9 +1322,9 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         int cap = 1024;
         while (cap < j * FILTER_STEP + 8 * FILTER_STEP * (int)std::ceil(std::sqrt((double)j))) cap *= 2;
         MfmaPlan ps, pf;
-        // measured crossover (benchmarks/run_filter_k.sh): nq = 64: filter mode wins from k = 16;
+        // measured crossover (benchmarks/ab/run_filter_k.sh): nq = 64: filter mode wins from k = 16;
         // nq = 1024 (one list per query and block): from k = 32
-        // stream kernel (nq <= 16, lists in registers; benchmarks/run_stream_k.sh): 1..3 queries
+        // stream kernel (nq <= 16, lists in registers; benchmarks/ab/run_stream_k.sh): 1..3 queries
         // list mode for every k <= 128 (the merge of the block lists costs ~10 us whatever k is:
         // nq 1, k 100: 2.23 ms against 2.28 in filter mode), 4..8 queries up to k = 64 (nq 8, k 100:
         // 3.0 ms against 2.48), 9..16 queries up to k ~ 16 (nq 16, k 32: 3.24 ms against 2.85)
@@ -1551,7 +1551,7 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         }
     }
 
-    // waves per CU (benchmarks/run_scan_threads_ab.sh): fp32 rows stream fastest with 12 (10M x 384:
+    // waves per CU (benchmarks/ab/run_scan_threads_ab.sh): fp32 rows stream fastest with 12 (10M x 384:
     // 2.19 ms against 2.215 ms with 16; 14 and 10 are slower), bfloat16 rows need 16 to cover the
     // unpacking (2.28 ms against 2.63 ms with 12)
     snprintf(h->last_kernel, sizeof h->last_kernel, "scan");

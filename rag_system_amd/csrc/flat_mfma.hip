@@ -39,7 +39,7 @@ using mfma::Shape;
 bool mfma_plan(long long n, long long nq, int k, bool bf16, MfmaPlan* p) {
     if (k > 128 || nq < 1 || n < 1) return false;
     const int KS = k > 64 ? 2 : 1;
-    int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));  // measured per batch size (benchmarks/run_nq64_sweep.sh)
+    int shape = nq > 128 ? 3 : (nq > 64 ? 2 : (nq > 32 ? 1 : 0));  // measured per batch size (benchmarks/ab/run_nq64_sweep.sh)
     const long long force = options().mfma_shape;
     if (force >= 1 && force <= 9) shape = (int)force - 1;  // 9: 64-query wave tiles
     if (KS == 2 && SHAPES[shape].WM * SHAPES[shape].WN > 4) shape = SHAPES[shape].BK == 32 ? 6 : 2;
@@ -86,7 +86,7 @@ bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p
     // more than 64 queries over bfloat16 rows of whole 128-byte lines: the pipelined kernel of
     // flat_mfma_pipe.h (config C3: 17.x ms per batch against 19.1 for shape 4; 65-128 queries, where its
     // 256-query tile is half empty: 10M x 768, k 100: 3.87-3.99 ms against 4.13-4.31 for the 128-query tile
-    // kernel, 10M x 384: 2.18-2.23 against 2.52-2.61; benchmarks/run_pipe_mid.sh)
+    // kernel, 10M x 384: 2.18-2.23 against 2.52-2.61; benchmarks/ab/run_pipe_mid.sh)
     if (nq > 64 && bf16 && ld_words > 0 && ld_words % 32 == 0) shape = 9;
     const long long force = options().mfma_shape;
     if ((force >= 1 && force <= 4) || (force >= 7 && force <= 10)) shape = (int)force - 1;

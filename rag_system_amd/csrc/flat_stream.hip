@@ -34,7 +34,7 @@
 // ONE block per CU: with little work per segment a wave only waits for its loads, and 4 waves x one
 // or two 4 KiB segments in flight per CU is where HBM delivers most -- 10M x 384, nq = 1: 7.23 TB/s
 // against 7.10 with 16 waves x 3 buffers; 8 or 16 KiB more in flight per wave only queue in the
-// memory system (benchmarks/run_stream_variants.sh, run_nb2_matrix.sh).  Shapes with more work per
+// memory system (benchmarks/ab/run_stream_variants.sh, run_nb2_matrix.sh).  Shapes with more work per
 // row (8+ queries, long lists) need the other waves of a SIMD to cover it and keep the deep ring.
 
 namespace rag {
@@ -633,14 +633,14 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     if (p->KS == 4) p->RG = 4;  // the only shape built with 256-entry lists
     // ring depth: see NB_LIGHT above ("stream_nb": 2 / 3 force one where both are built)
     const bool light_built = p->G == 1 && p->RG == 4 && (filt || p->KS == 1);  // filter mode is built with KS = 1
-    // measured (benchmarks/run_nb_k.sh, 10M x 384): nq 1: k 10 / 32 / 64 = 2.142 / 2.157 / 2.175 ms against
+    // measured (benchmarks/ab/run_nb_k.sh, 10M x 384): nq 1: k 10 / 32 / 64 = 2.142 / 2.157 / 2.175 ms against
     // 2.191-2.196; nq 4: k 10 2.173 against 2.197, k 20 a tie, k 32 and nq 3 k 64 lose 1.5-3 % (the one
     // wave of a SIMD also carries every list insert); filter pass nq 4 k 100: 2.318 against 2.354.
     // 1M rows: nq 1 k 10 0.240 against 0.246 ms; nq 4 k 30 0.307 against 0.265 (list warm-up)
     const long long list_load = nq * (long long)k;
     // rows of up to three 256-byte segments (384 bfloat16 values: the copy of rag_flat_prefilter): a tile is over
     // after three steps and the epilogue's fold + inserts stall a ring of two (10M x 384 bf16, nq 1, k 64:
-    // 1.354 ms with the light shape, 1.086 with the deep ring = 7.07 TB/s; benchmarks/run_prefilter_opts.sh)
+    // 1.354 ms with the light shape, 1.086 with the deep ring = 7.07 TB/s; benchmarks/ab/run_prefilter_opts.sh)
     const bool short_rows = dch <= 48;
     const bool light_auto = !short_rows && (filt || (list_load <= 64 && (n >= (4LL << 20) || list_load <= 16)));
     p->NB = light_built && (opt.stream_nb == NB_LIGHT || (opt.stream_nb == 0 && light_auto)) ? NB_LIGHT : NB_DEFAULT;
@@ -656,7 +656,7 @@ bool stream_plan(long long n, long long nq, int k, int dch, bool bf16, bool filt
     const long long bpc = opt.stream_bpc > 0 ? opt.stream_bpc
                           : p->NB == NB_LIGHT ? 1
                           // long lists for one or two queries: two blocks per CU (nq 1, k 100: 2.195 against
-                          // 2.207 ms with four; 1M rows, k 90: 0.252 against 0.263; benchmarks/run_less_inflight.sh)
+                          // 2.207 ms with four; 1M rows, k 90: 0.252 against 0.263; benchmarks/ab/run_less_inflight.sh)
                           : (p->G == 1 && nq <= 2) ? 2
                                                    : (p->G * p->RG >= 8 ? 3 : 4);  // = the kernel's launch bound
     long long blocks = std::min<long long>((long long)num_cus() * bpc, (ntiles + ST_WAVES - 1) / ST_WAVES);

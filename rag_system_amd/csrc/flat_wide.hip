@@ -366,7 +366,7 @@ bool wide_plan(long long n, long long nq, int dch, bool bf16, int j, int cap, in
     // Ring depth: rows are padded to a multiple of NB 128-byte steps.  Up to two query tiles the default is 4;
     // rows of 6 steps (384 bfloat16 values -- the copy of rag_flat_prefilter) then run 8.  The padding steps are
     // cheap (their loads re-read a cached chunk), so the shorter ring only pays with two query tiles (10M x 384
-    // bf16: 32 queries 1.319 ms against 1.381, 16 queries 1.439 against 1.399; benchmarks/run_prefilter_mid.sh).
+    // bf16: 32 queries 1.319 ms against 1.381, 16 queries 1.439 against 1.399; benchmarks/ab/run_prefilter_mid.sh).
     p->nb = wide_nb(p->NT);
     if (p->NT == 2 && wide_nstep(dch, 3) < wide_nstep(dch, p->nb)) p->nb = 3;
     if (opt.wide_nb == 3 && p->NT <= 2) p->nb = 3;

@@ -212,8 +212,7 @@ class SearchEngine:
         if "faiss" not in self.vector_storage.indices_present or not queries:
             return [[] for _ in queries]
         k = top_k * 3 if retrieval_mode == "document" else top_k
-        q_vecs = np.stack([np.asarray(self.embedding_manager.embed_query(q), dtype="float32").reshape(-1)
-                           for q in queries])
+        q_vecs = self._embed_queries(queries)
         out = []
         for query, hits in zip(queries, self.vector_storage.search_batch(q_vecs, top_k=k)):
             for r in hits:
@@ -228,6 +227,31 @@ class SearchEngine:
             results.sort(key=lambda x: x["score"], reverse=True)
             out.append(results[:top_k])
         return out
+
+    def _embed_queries(self, queries):
+        """(nq, d) float32 query embeddings with ONE model.encode call for the whole batch, normalised row by row
+        as embed_query does (embedding_manager.py:88-98: float32, divided by the norm, a norm below 1e-9 counts as
+        1).  Managers that offer embed_queries are asked directly; managers without a batch-capable model fall
+        back to embed_query per query."""
+        em = self.embedding_manager
+        batch = getattr(em, "embed_queries", None)
+        if batch is not None:
+            return np.ascontiguousarray(batch(queries), dtype="float32").reshape(len(queries), -1)
+        model = getattr(em, "model", None)
+        if model is not None and hasattr(model, "encode"):
+            try:
+                vecs = np.array(model.encode(list(queries)), dtype="float32")
+            except Exception as e:       # a model that takes one text at a time
+                self._debug("batched encode failed (%s): one embed_query per query" % e)
+                vecs = None
+            if vecs is not None and vecs.ndim == 2 and vecs.shape[0] == len(queries):
+                for i in range(len(vecs)):
+                    norm = np.linalg.norm(vecs[i])
+                    if norm < 1e-9:
+                        norm = 1.0
+                    vecs[i] /= norm
+                return vecs
+        return np.stack([np.asarray(em.embed_query(q), dtype="float32").reshape(-1) for q in queries])
 
     def search_bm25(self, query: str, top_k=10, retrieval_mode="document", _want_text=True) -> List[Dict[str, Any]]:
         if "bm25" not in self.vector_storage.indices_present:

@@ -247,6 +247,37 @@ def _run_batch_front_end():
                 assert [r.get("chunk", r.get("text")) for r in g] == [r.get("chunk", r.get("text")) for r in exp]
                 assert np.allclose([r["score"] for r in g], [r["score"] for r in exp], rtol=1e-5, atol=2e-6)
     assert eng.search_faiss_batch([], 5) == []
+    # ONE model.encode call for the whole batch (f2: "pipelined with embed_query batches"), rows normalised as
+    # embed_query normalises them (embedding_manager.py:88-98) -> bit-identical query vectors
+    calls = []
+    real_encode = em.model.encode
+
+    def counting_encode(texts, *a, **kw):
+        calls.append(1 if isinstance(texts, str) else len(texts))
+        return real_encode(texts, *a, **kw)
+    em.model.encode = counting_encode
+    try:
+        got = eng.search_faiss_batch(queries + ["zzzz qqqq"], top_k=5, retrieval_mode="chunk")
+        assert calls == [len(queries) + 1], calls
+        vecs = eng._embed_queries(queries + ["zzzz qqqq"])
+        for q, v in zip(queries + ["zzzz qqqq"], vecs):
+            assert v.tobytes() == np.asarray(em.embed_query(q), dtype="float32").tobytes()
+    finally:
+        em.model.encode = real_encode
+    assert len(got) == len(queries) + 1
+
+    class OneAtATime:                       # a manager whose model cannot take a list: the per-query loop
+        model_name, chunk_size, overlap = em.model_name, em.chunk_size, em.overlap
+
+        class model:                        # noqa: N801
+            @staticmethod
+            def encode(texts):
+                if not isinstance(texts, str) and len(texts) != 1:
+                    raise TypeError("one text at a time")
+                return real_encode(texts)
+        embed_query = staticmethod(em.embed_query)
+    eng1 = SearchEngine(store, OneAtATime())
+    assert eng1.search_faiss_batch(queries[:3], 5) == eng.search_faiss_batch(queries[:3], 5)
 
 
 def test_batch_front_end_cpu_oracle_backend():

@@ -201,3 +201,16 @@ def test_postings_form_of_bm25_equals_dict_form():
         tids = [vocab[w] for w in q if w in vocab]
         got = osp.bm25_scores_postings(indptr, np.array(rows), np.array(tf), idf, ref.doc_len, ref.avgdl, 1.0, 0.65, tids)
         assert got.tobytes() == ref.get_scores(q).tobytes()
+
+
+def test_check_topk_rejects_a_repeated_id():
+    """A duplicate id that scores within tolerance of the oracle's entry must not pass as a near-tie."""
+    import pytest
+    D = np.array([[3.0, 2.0, 2.0]])
+    I_ref = np.array([[5, 7, 8]])
+    od.check_topk(D, I_ref, D, I_ref)
+    with pytest.raises(AssertionError, match="more than once"):
+        od.check_topk(D, np.array([[5, 7, 7]]), D, I_ref)
+    pad = np.array([[5, -1, -1]])
+    Dp = np.array([[3.0, -3.4028234663852886e38, -3.4028234663852886e38]])
+    od.check_topk(Dp, pad, Dp, pad)      # pads repeat by construction
