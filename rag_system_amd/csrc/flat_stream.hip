@@ -526,6 +526,14 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
     if (D == nullptr) return;  // uniform: the caller merges the lists with flat_merge_kernel
     // ---- fused merge: every storing wave drains its (write-through) stores, the block's barrier, then ONE
     // lane draws the ticket; the last arriver acquires and reads every block's lists
+#ifndef RAG_FUSE_STRICT
+    // Relaxed ticket, write-through (sc1) list stores drained by every wave before the block's barrier, ONE explicit
+    // acquire by the last arriver, plain loads behind it (sc1 loads and no acquire: 18 us -- thousands of uncached
+    // 4-byte reads of a 25 KB region against 200 cache lines).  This leans on what sc1 stores and s_waitcnt do on
+    // gfx950 rather than on the HIP memory model; the model-conformant variant below (-DRAG_FUSE_STRICT) was
+    // measured 5-9 us per launch slower (r03, benchmarks/ab/run_r03_fuse.sh: 2.1398 -> 2.1486 ms at 10M rows,
+    // 0.2468 -> 0.2515 ms at 1M: the release half of every block's ticket draw writes the XCD's L2 back), so this
+    // one stays, guarded by tests/test_flat_stream_gpu.py::test_fused_merge_never_reads_a_stale_list.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* last = reinterpret_cast<int*>(smem_raw + FUSE_SMEM - 16);
@@ -534,13 +542,26 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
         const bool is_last = t == gridDim.x - 1;
         if (is_last) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-            // plain loads behind ONE acquire: reading the lists with sc1 loads instead (no fence) took 18 us --
-            // thousands of uncached 4-byte reads of a 25 KB region, against 200 cache lines this way
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         *last = is_last ? 1 : 0;
     }
+#else
+    // Inside the HIP memory model (build with -DRAG_FUSE_STRICT): the block's barrier orders every lane's list stores before lane 0's ticket
+    // draw, which is an acq_rel read-modify-write at agent scope -- its release half publishes what happened
+    // before it in this block (cumulativity across the barrier), its acquire half, in the block that draws the
+    // last ticket, makes every earlier block's publication visible; the barrier behind it extends that to the
+    // other lanes of the last block, which then read the lists with plain loads.
+    __syncthreads();
+    int* last = reinterpret_cast<int*>(smem_raw + FUSE_SMEM - 16);
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const bool is_last = t == gridDim.x - 1;
+        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+        *last = is_last ? 1 : 0;
+    }
+#endif
     __syncthreads();
     if (*last == 0) return;
     __syncthreads();  // *last is read by everyone before the merge reuses the LDS

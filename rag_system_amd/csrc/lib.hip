@@ -1,6 +1,7 @@
 // lib.hip -- process-level state of librag_mi355x.so: device selection, error text, options.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace rag {
@@ -68,6 +69,13 @@ int rag_init(int device_id) {
                          "already initialised on device %d (one process per GPU)", rag::g_dev);
     }
     RAG_HIP(hipSetDevice(device_id));
+    // RAG_SYNC_MODE=spin|yield|block (experiment switch): how hipStreamSynchronize waits on this device
+    if (const char* m = std::getenv("RAG_SYNC_MODE")) {
+        unsigned flags = !std::strcmp(m, "spin") ? hipDeviceScheduleSpin : !std::strcmp(m, "yield") ? hipDeviceScheduleYield
+                         : !std::strcmp(m, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        (void)hipSetDeviceFlags(flags);
+        (void)hipGetLastError();
+    }
     hipDeviceProp_t prop;
     RAG_HIP(hipGetDeviceProperties(&prop, device_id));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)

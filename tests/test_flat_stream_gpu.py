@@ -277,3 +277,59 @@ def test_fused_merge_equals_merge_kernel(engine, metric, storage):
         assert np.array_equal(Id.cpu().numpy(), I + 7_000_000_000) and np.array_equal(Dd.cpu().numpy(), D)
     finally:
         _opts(lib, stream_fuse=0)
+
+
+def test_fused_merge_never_reads_a_stale_list(engine):
+    """The last block of the stream kernel merges the block lists the other blocks wrote in the same launch; the
+    hand-off (write-through stores, a ticket, one acquire) leans on hardware behaviour outside the HIP memory
+    model.  This test makes a stale read VISIBLE instead of lucky: one handle whose
+    workspace is reused by corpora of different size (300k, 20k and 2k rows: 256, 256 and fewer block lists)
+    and by queries with disjoint answers, many searches enqueued back to back on one stream with no host
+    synchronisation between them, every result compared with the separate merge kernel's.  A list left over
+    from the previous launch -- another corpus, another query -- would surface as a foreign id or score."""
+    import ctypes as C
+    import torch
+    from rag_system_amd import _lib, faiss_compat as faiss
+    lib = _lib.engine()
+    rng = np.random.default_rng(99)
+    d, k, nrep = 64, 10, 12
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(dev)
+    corpora = []
+    for n in (300_000, 20_000, 2_000):
+        X = _rand_unit(rng, n, d)
+        Q = _rand_unit(rng, 6, d)
+        for j in range(6):                   # each query has its own planted neighbourhood, far from the others'
+            X[rng.choice(n, 12, replace=False)] = (Q[j] + 0.05 * _rand_unit(rng, 12, d)).astype(np.float32)
+        corpora.append((X, Q))
+    idx = faiss.IndexFlatIP(d)
+    try:
+        for rnd in range(6):
+            X, Q = corpora[rnd % 3]
+            idx.reset()
+            idx.add(X)
+            _opts(lib, stream_fuse=-1)
+            ref = [idx.search(Q[j:j + 1], k) for j in range(6)]          # merge kernel (also flushes the rows)
+            assert "fused-merge" not in idx._b.last_kernel()
+            _opts(lib, stream_fuse=0)
+            with torch.cuda.stream(st):
+                qd = torch.from_numpy(Q).to(dev)
+                Dd = torch.full((nrep * 6, k), -7.0, dtype=torch.float32, device=dev)
+                Id = torch.full((nrep * 6, k), -7, dtype=torch.int64, device=dev)
+            st.synchronize()
+            for r in range(nrep):             # 72 launches back to back, alternating queries, no host sync
+                for j in range(6):
+                    slot = r * 6 + j
+                    _lib.check(lib.rag_flat_search_dev(idx._b._h, 1, C.c_void_p(qd[j].data_ptr()), k,
+                                                       C.c_void_p(Dd[slot].data_ptr()), C.c_void_p(Id[slot].data_ptr()), 0,
+                                                       C.c_void_p(st.cuda_stream)), lib)
+            assert "fused-merge" in idx._b.last_kernel(), idx._b.last_kernel()
+            st.synchronize()
+            Dh, Ih = Dd.cpu().numpy(), Id.cpu().numpy()
+            for r in range(nrep):
+                for j in range(6):
+                    D0, I0 = ref[j]
+                    assert np.array_equal(Ih[r * 6 + j], I0[0]), (rnd, r, j)
+                    assert np.array_equal(Dh[r * 6 + j].view(np.uint32), D0[0].view(np.uint32)), (rnd, r, j)
+    finally:
+        _opts(lib, stream_fuse=0)
