@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
     ap.add_argument("--cpu-queries", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--check-queries", type=int, default=8, help="queries checked against oracle/ after the timed loop")
     ap.add_argument("--search-engine", action="store_true",
                     help="also time the queries through rag_system_amd.SearchEngine on a VectorStorage over the same indices")
     ap.add_argument("--no-tail", action="store_true", help="the three-call route instead of rag_hybrid_rrf_mmr")
@@ -68,7 +69,7 @@ def main():
     sparse_bytes = {"bm25": 0.0, "tfidf": 0.0}
     results = []
     log("warm-up")
-    for qi in range(min(3, args.queries)):
+    for qi in range(min(10, args.queries)):     # first calls size workspaces and set kernel attributes
         wl.query(qi, tail=not args.no_tail)
     log("timing %d queries" % args.queries)
     prof = None
@@ -89,7 +90,7 @@ def main():
     per_stage_ms = {s: tsum[s] / nq * 1e3 for s in stages}
 
     # ---- parity at full size against the numpy restatement (oracle/)
-    ncheck = min(8, args.queries)
+    ncheck = min(args.check_queries, args.queries)
     log("parity check against oracle/ on %d queries" % ncheck)
     checked = wl.check(list(range(ncheck)), results[:ncheck])
 

@@ -240,6 +240,13 @@ int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks
  * search_engine.py:286 builds a dict over ALL documents, of which the fusion
  * (:301-311) only reads the candidates' entries. */
 int rag_csc_gather(rag_csc_t* h, int n_query, const int64_t* rows, double* out_scores);
+/* counts[i] = number of rows j of the LAST score vector with (score_j > keys[i]) or (score_j == keys[i] and
+ * j < ids[i]): how many rows of this index stand ahead of an arbitrary (score, id) pair in the stable descending
+ * order of vector_storage.py:180 / search_engine.py:332-336.  ids are in this index' row numbering and may lie
+ * outside [0, n_rows) -- rows of ANOTHER shard (id - this shard's first row): a document's rank in a row-sharded
+ * index is the sum of its count over the shards ("sparse indices shard the same way by document
+ * rows").  With a pair that is one of this index' own rows this is rag_csc_ranks. */
+int rag_csc_count_ahead(rag_csc_t* h, int n, const double* keys, const int64_t* ids, int64_t* counts);
 /* rag_tfidf_scores (top-k only) + rag_csc_ranks + rag_csc_gather in ONE call and one
  * synchronisation: what a hybrid query needs from the TF-IDF ranking (search_engine.py:284-286 scores
  * and :332-336 ranks ALL documents; the fusions at :301-311 / :338-345 read the head of the ranking and

@@ -85,6 +85,7 @@ SIGNATURES = {
     "rag_tfidf_scores": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int, _p, _p]),
     "rag_csc_ranks": (C.c_int, [_p, C.c_int, _p, _p]),
     "rag_csc_gather": (C.c_int, [_p, C.c_int, _p, _p]),
+    "rag_csc_count_ahead": (C.c_int, [_p, C.c_int, _p, _p, _p]),
     "rag_tfidf_query": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, _p, _p, C.c_int, _p, _p, _p]),
     "rag_tfidf_query_begin": (C.c_int, [_p, C.c_int, _p, _p, C.c_int]),
     "rag_tfidf_query_end": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, _p, _p, _p]),

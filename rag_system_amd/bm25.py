@@ -80,6 +80,15 @@ class _HipCsc:
         _lib.check(self._lib.rag_csc_gather(self._h, len(r), _lib.ptr(r), _lib.ptr(out)), self._lib)
         return out
 
+    def count_ahead(self, keys, ids):
+        """rag_csc_count_ahead: per (score, id) pair, how many rows of the last score vector stand ahead of it
+        (ids in this index' row numbering, possibly outside it: another shard's rows)."""
+        kk = np.ascontiguousarray(keys, dtype=np.float64)
+        ii = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty(len(kk), dtype=np.int64)
+        _lib.check(self._lib.rag_csc_count_ahead(self._h, len(kk), _lib.ptr(kk), _lib.ptr(ii), _lib.ptr(out)), self._lib)
+        return out
+
     MAX_QUERY_ROWS = 1024
 
     def tfidf_query(self, term_ids, weights, k, rows, want_scores=True):
@@ -195,11 +204,15 @@ class BM25Okapi:
 
     MAX_FUSED_K = _lib.MAX_K
 
-    def __init__(self, corpus, tokenizer=None, k1=1.5, b=0.75, epsilon=0.25):
+    def __init__(self, corpus, tokenizer=None, k1=1.5, b=0.75, epsilon=0.25, shard=None):
+        """shard=(first, count) (not in rank_bm25; rag_system_amd.sharded): the statistics -- idf, avgdl -- are
+        those of the WHOLE corpus, but only the postings of documents [first, first + count) are uploaded, as
+        local rows 0 .. count-1 (get_scores / top_k then cover this block only)."""
         self.k1 = k1
         self.b = b
         self.epsilon = epsilon
         self.tokenizer = tokenizer
+        self._shard = shard
         if tokenizer:
             corpus = [tokenizer(doc) for doc in corpus]
         self.corpus_size = 0
@@ -265,6 +278,7 @@ class BM25Okapi:
         keep_postings: keep the host copy of the term-major postings as self.postings =
         (indptr, rows, tf) (benchmarks cross-check full-size results with it)."""
         self = cls.__new__(cls)
+        self._shard = None
         self._keep_postings = keep_postings
         self.k1, self.b, self.epsilon, self.tokenizer = k1, b, epsilon, None
         doc_indptr = np.asarray(doc_indptr, dtype=np.int64)
@@ -323,8 +337,24 @@ class BM25Okapi:
         self._idf_arr = idf
         if getattr(self, "_keep_postings", False):
             self.postings = (indptr, rows, tf)
-        self._csc = make_csc(len(words), n, indptr, rows, tf)
-        self._csc.bm25_set(idf, np.asarray(self.doc_len, dtype=np.int32), self.avgdl, self.k1, self.b)
+        doc_len = np.asarray(self.doc_len, dtype=np.int32)
+        self.n_local = n
+        shard = getattr(self, "_shard", None)
+        if shard is not None:       # this rank's block of the rows: filter the (term-major, row-ascending) postings
+            lo, cnt = int(shard[0]), int(shard[1])
+            rows = np.asarray(rows)
+            keep = (rows >= lo) & (rows < lo + cnt)
+            csum = np.concatenate([np.zeros(1, np.int64), np.cumsum(keep, dtype=np.int64)])
+            indptr = csum[np.asarray(indptr, dtype=np.int64)]
+            rows = (rows[keep] - lo).astype(np.int32)
+            tf = np.asarray(tf)[keep]
+            doc_len = doc_len[lo:lo + cnt]
+            self.n_local = cnt
+            if cnt == 0:
+                self._csc = None
+                return
+        self._csc = make_csc(len(words), self.n_local, indptr, rows, tf)
+        self._csc.bm25_set(idf, doc_len, self.avgdl, self.k1, self.b)
 
     def _term_ids(self, query):
         # out-of-vocabulary tokens add (idf.get(q) or 0) * 0 = 0: dropped.  Repeats stay.
@@ -339,7 +369,7 @@ class BM25Okapi:
     def top_k(self, query, k):
         """(ids, scores) of the first k entries of sorted(range(n), key=scores, reverse=True)
         (vector_storage.py:180) without materialising the score vector on the host."""
-        k = min(int(k), self.corpus_size)
+        k = min(int(k), getattr(self, "n_local", self.corpus_size))
         if k <= 0:
             return np.empty(0, np.int64), np.empty(0, np.float64)
         if k > self.MAX_FUSED_K:

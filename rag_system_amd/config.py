@@ -6,7 +6,7 @@ store / UI settings are kept as plain attributes so callers that read them keep 
 Unlike the reference (config.py:37-39 sets the BM25 / MMR constants only inside the
 file-exists branch of load()), they are class attributes here and always defined.
 
-Engine keys (no counterpart in the reference): ENGINE_DEVICE.
+Engine keys (no counterpart in the reference): ENGINE_DEVICE, ENGINE_SHARD.
 """
 import json
 import os
@@ -27,6 +27,10 @@ class Config:
     BM25_PARAM_B = 0.65
     MMR_PARAM_LAMBDA = 0.85
     ENGINE_DEVICE = None  # HIP ordinal; None = $RAG_MI355X_DEVICE / $LOCAL_RANK / 0
+    # Row sharding over the GPUs of one node, one process per GPU (rag_system_amd.sharded):
+    # "auto" = VectorStorageManager.load_storage shards over torch.distributed's ranks when a process group with
+    # more than one rank is initialised; True / False force it.
+    ENGINE_SHARD = "auto"
 
     _KEYS = ("BASE_DIR", "EMBEDDING_MODEL_KEY", "CHUNK_SIZE", "OVERLAP", "CROSS_ENCODER_MODEL", "DEFAULT_TOP_K",
              "DEFAULT_THRESHOLD", "UI_LAST_STORE", "DEFAULT_RETRIEVAL_MODE", "MIN_CHUNKS")

@@ -350,13 +350,24 @@ __global__ __launch_bounds__(RANK_MAXQ) void rank_prep_kernel(const double* __re
                                                               const long long* __restrict__ qrow,
                                                               double* __restrict__ skey, long long* __restrict__ srow,
                                                               int* __restrict__ pos_of, unsigned long long* __restrict__ hist,
-                                                              double* __restrict__ gather_out = nullptr) {
+                                                              double* __restrict__ gather_out = nullptr,
+                                                              const double* __restrict__ pair_key = nullptr,
+                                                              long long n = 0) {
     __shared__ double ks[RANK_MAXQ];
     __shared__ long long rs[RANK_MAXQ];
     const int i = threadIdx.x;
+    bool foreign = false;
     if (i < nq) {
         rs[i] = qrow[i];
-        ks[i] = score[qrow[i]];
+        if (pair_key != nullptr) {
+            // rag_csc_count_ahead: explicit (score, id) pairs, ids in this vector's row numbering but possibly
+            // outside [0, n) -- another shard's rows.  Only a pair that IS one of this vector's rows counts itself
+            // in the histogram below and has 1 subtracted by rank_final_kernel.
+            ks[i] = pair_key[i];
+            foreign = !(rs[i] >= 0 && rs[i] < n && score[rs[i]] == ks[i]);
+        } else {
+            ks[i] = score[qrow[i]];
+        }
         if (gather_out != nullptr) gather_out[i] = ks[i];  // rag_tfidf_query_end: the queried rows' scores (pinned memory)
     }
     if (i < nq) hist[i] = 0;
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(RANK_MAXQ) void rank_prep_kernel(const double* __re
             pos += (pair_ahead(ks[j], rs[j], k, r) || (ks[j] == k && rs[j] == r && j < i)) ? 1 : 0;
         skey[pos] = k;
         srow[pos] = r;
-        pos_of[i] = pos;
+        pos_of[i] = pos | (foreign ? (1 << 30) : 0);
     }
 }
 
@@ -425,7 +436,10 @@ __global__ __launch_bounds__(RANK_MAXQ) void rank_final_kernel(const unsigned lo
         }
     }
     __syncthreads();
-    if (i < nq) rank[i] = pre[pos_of[i]] - 1ULL;
+    if (i < nq) {
+        const int p = pos_of[i];
+        rank[i] = pre[p & ((1 << 30) - 1)] - ((p >> 30) & 1 ? 0ULL : 1ULL);
+    }
 }
 
 // The three kernels above in ONE launch, for up to RANK1_MAXQ queried rows (rag_tfidf_query_end: a hybrid query
@@ -1822,6 +1836,36 @@ int rag_csc_ranks(rag_csc_t* h, int n_query, const int64_t* rows, int64_t* ranks
         RAG_HIP(hipMemcpyAsync(h->pin + PIN_BYTES / 2, h->rk_out, (size_t)nq * sizeof(long long), hipMemcpyDeviceToHost, st));
         RAG_HIP(hipStreamSynchronize(st));
         std::memcpy(ranks + q0, h->pin + PIN_BYTES / 2, (size_t)nq * sizeof(long long));
+    }
+    return RAG_OK;
+}
+
+int rag_csc_count_ahead(rag_csc_t* h, int n, const double* keys, const int64_t* ids, int64_t* counts) {
+    RAG_REQUIRE_INIT();
+    if (!h || n < 0 || (n > 0 && (!keys || !ids || !counts))) return fail(RAG_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->begun_k) return fail(RAG_ERR_INVALID_ARG, "a TF-IDF query is begun on this handle: end it first (rag_tfidf_query_end)");
+    if (!h->have_scores) return fail(RAG_ERR_INVALID_ARG, "no score vector has been computed on this handle");
+    hipStream_t st = lib_stream();
+    if (!h->pin) RAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pin), PIN_BYTES, hipHostMallocDefault));
+    if (!h->rk_gather) RAG_HIP(hipMalloc(&h->rk_gather, RANK_MAXQ * sizeof(double)));
+    for (int q0 = 0; q0 < n; q0 += RANK_MAXQ) {
+        const int nq = std::min(RANK_MAXQ, n - q0);
+        std::memcpy(h->pin, ids + q0, (size_t)nq * sizeof(long long));
+        std::memcpy(h->pin + PIN_Q_SCORES, keys + q0, (size_t)nq * sizeof(double));
+        RAG_HIP(hipMemcpyAsync(h->rk_rows, h->pin, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, st));
+        RAG_HIP(hipMemcpyAsync(h->rk_gather, h->pin + PIN_Q_SCORES, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, st));
+        long long nb = (h->n_rows + 2047) / 2048;
+        nb = std::max<long long>(1, std::min<long long>(nb, (long long)num_cus() * 4));
+        rank_prep_kernel<<<1, RANK_MAXQ, 0, st>>>(h->score, nq, h->rk_rows, h->rk_skey, h->rk_srow, h->rk_pos, h->rk_hist,
+                                                  nullptr, h->rk_gather, (long long)h->n_rows);
+        rank_hist_kernel<<<(unsigned)nb, 256, 0, st>>>(h->score, (long long)h->n_rows, nq, h->rk_skey, h->rk_srow,
+                                                      h->rk_hist);
+        rank_final_kernel<<<1, RANK_MAXQ, 0, st>>>(h->rk_hist, nq, h->rk_pos, h->rk_out);
+        RAG_HIP(hipGetLastError());
+        RAG_HIP(hipMemcpyAsync(h->pin + PIN_BYTES / 2, h->rk_out, (size_t)nq * sizeof(long long), hipMemcpyDeviceToHost, st));
+        RAG_HIP(hipStreamSynchronize(st));
+        std::memcpy(counts + q0, h->pin + PIN_BYTES / 2, (size_t)nq * sizeof(long long));
     }
     return RAG_OK;
 }

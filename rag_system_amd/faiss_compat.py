@@ -264,7 +264,9 @@ def write_index(index, path):
             f.write(index.reconstruct_n(first, cnt).astype("<f4", copy=False).tobytes())
 
 
-def read_index(path):
+def read_index(path, first=0, count=None):
+    """first / count (not in faiss): read only rows [first, first + count) of the file -- one rank's block of a
+    row-sharded store (rag_system_amd.sharded), so that a 300 GB matrix is never held by one GPU."""
     with open(path, "rb") as f:
         hdr = f.read(_HDR.size)
         if len(hdr) != _HDR.size:
@@ -276,12 +278,16 @@ def read_index(path):
             raise ValueError("%s: unsupported metric_type %d" % (path, metric))
         if fourcc == b"IxFI" and metric != METRIC_INNER_PRODUCT or fourcc == b"IxF2" and metric != METRIC_L2:
             raise ValueError("%s: fourcc %r contradicts metric_type %d" % (path, fourcc, metric))
-        (count,) = struct.unpack("<Q", f.read(8))
-        if count != ntotal * d:
-            raise ValueError("%s: vector payload size %d != ntotal*d = %d" % (path, count, ntotal * d))
+        (n_values,) = struct.unpack("<Q", f.read(8))
+        if n_values != ntotal * d:
+            raise ValueError("%s: vector payload size %d != ntotal*d = %d" % (path, n_values, ntotal * d))
         index = IndexFlat(d, metric)
         step = max(1, (64 << 20) // (4 * d))
-        left = ntotal
+        first = max(0, min(int(first), ntotal))
+        left = ntotal - first if count is None else max(0, min(int(count), ntotal - first))
+        index.file_ntotal = ntotal          # rows in the file (= ntotal unless a block was asked for)
+        if first:
+            f.seek(first * d * 4, 1)
         while left > 0:
             cnt = min(step, left)
             buf = f.read(cnt * d * 4)

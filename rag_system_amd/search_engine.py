@@ -600,8 +600,8 @@ class SearchEngine:
                 table.setdefault((cd["doc_id"], cd["chunk"]), i)
             cache = (len(st.chunks_data), table)
             st._chunk_row_map = cache
-        if st.index.ntotal != len(st.chunks_data):
-            return None
+        if st.index.ntotal != len(st.chunks_data) or getattr(st.index, "sharded", False):
+            return None     # (a row-sharded index cannot gather arbitrary rows on one GPU: re-encode)
         rows = []
         for r in results:
             # a chunk hit, or a document entry whose text IS one stored chunk (a one-chunk document: the text

@@ -183,3 +183,239 @@ class ShardedFlatSearcher:
         finally:
             self.stage_events = None
         return {"scan_ms": acc[0] / steps, "allgather_ms": acc[1] / steps, "merge_ms": acc[2] / steps}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Sharding behind the drop-in API: one process per GPU, every rank holds the
+# SAME host metadata (chunks_data, documents: strings) and ITS block of the numeric indices -- a contiguous block
+# of dense rows, and of the BM25 / TF-IDF postings the block of document rows.  Every call below is SPMD: all ranks
+# make it with the same arguments and all ranks get the same result.
+
+
+class ShardContext:
+    """Which rank of how many this process is, and the torch.distributed group the exchange goes through.
+    Without an initialised process group: one rank (the wrappers then behave like the plain indices)."""
+
+    def __init__(self, group=None, device=None, force_exchange=False):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self.group = torch, dist, group
+        # force_exchange: a ONE-rank group still goes through the collectives (the rehearsal of the real transport
+        # on a one-GPU box, tests/test_sharded_rccl_gpu.py)
+        self.force_exchange = bool(force_exchange)
+        if dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            backend = dist.get_backend(group)
+        else:
+            self.rank, self.world, backend = 0, 1, None
+        if device is None:      # RCCL moves device tensors, gloo host tensors
+            device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        self.device = torch.device(device)
+
+    def all_gather(self, arr):
+        """numpy array (same shape and dtype on every rank) -> array [world, ...] (the path's one exchange step)."""
+        import numpy as np
+        arr = np.ascontiguousarray(arr)
+        if self.world == 1 and not (self.force_exchange and self._dist.is_initialized()):
+            return arr[None]
+        torch = self._torch
+        t = torch.from_numpy(arr).to(self.device)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=self.device)
+        self._dist.all_gather_into_tensor(out.view(-1), t.reshape(-1), group=self.group)
+        return out.cpu().numpy()
+
+    def all_reduce_sum(self, arr):
+        import numpy as np
+        arr = np.ascontiguousarray(arr)
+        if self.world == 1 and not (self.force_exchange and self._dist.is_initialized()):
+            return arr
+        t = self._torch.from_numpy(arr.copy()).to(self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+
+def merge_topk_host(scores, ids, k, larger_is_better=True):
+    """[G, nq, kk] candidate lists (ids < 0 = padding) -> ([nq, k] scores, [nq, k] ids): best score first, lower id
+    first on ties -- the order of faiss's result lists and of Python's stable descending sort (vector_storage.py:180);
+    short results are padded with id -1 / the worst score."""
+    import numpy as np
+    G, nq, kk = scores.shape
+    s = np.moveaxis(scores, 0, 1).reshape(nq, G * kk)
+    i = np.moveaxis(ids, 0, 1).reshape(nq, G * kk)
+    D = np.empty((nq, k), dtype=scores.dtype)
+    I = np.empty((nq, k), dtype=np.int64)
+    worst = -np.inf if larger_is_better else np.inf
+    if scores.dtype == np.float32:
+        worst = -np.finfo(np.float32).max if larger_is_better else np.finfo(np.float32).max
+    for q in range(nq):
+        pad = i[q] < 0
+        key = -s[q] if larger_is_better else s[q]
+        order = np.lexsort((i[q], key, pad))[:k]
+        order = order[~pad[order]]
+        D[q, :len(order)] = s[q][order]
+        I[q, :len(order)] = i[q][order]
+        D[q, len(order):] = worst
+        I[q, len(order):] = -1
+    return D, I
+
+
+class ShardedIndexFlat:
+    """faiss.IndexFlat surface (ntotal, add, search, d, metric_type) over ONE rank's block of the rows.
+    Global row ids = first_row + local row; rows added later go to the LAST rank (ids stay contiguous)."""
+    sharded = True
+
+    def __init__(self, local, first_row, ntotal, ctx):
+        self.local, self.first_row, self._ntotal, self.ctx = local, int(first_row), int(ntotal), ctx
+        self.d, self.metric_type, self.is_trained = local.d, local.metric_type, True
+        self._searchers = {}
+
+    @property
+    def ntotal(self):
+        return self._ntotal
+
+    def add(self, x):
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError("add expects a (n, %d) float32 array, got %s" % (self.d, x.shape))
+        if self.ctx.rank == self.ctx.world - 1:
+            if self.local.ntotal == 0:
+                self.first_row = self._ntotal       # an empty last block starts where the index ends
+            self.local.add(x)
+        self._ntotal += x.shape[0]
+
+    def _device_searcher(self, nq, k):
+        key = (nq, k)
+        s = self._searchers.get(key)
+        if s is None:
+            torch = self.ctx._torch
+            b = self.local._b
+
+            def local_search(q, kk, D_loc, I_loc, st):
+                b.search_dev(nq, q.data_ptr(), kk, D_loc.data_ptr(), I_loc.data_ptr(), self.first_row, st)
+            s = ShardedFlatSearcher(local_search, self.metric_type, nq, k, self.ctx.device, group=self.ctx.group,
+                                    stream=torch.cuda.Stream(self.ctx.device), force_exchange=self.ctx.force_exchange)
+            if len(self._searchers) > 16:
+                self._searchers.clear()
+            self._searchers[key] = s
+        return s
+
+    def search(self, x, k):
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError("search expects a (nq, %d) float32 array, got %s" % (self.d, x.shape))
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        nq = x.shape[0]
+        if nq == 0:
+            return np.empty((0, k), dtype=np.float32), np.empty((0, k), dtype=np.int64)
+        if self.ctx.device.type == "cuda" and hasattr(self.local._b, "search_dev"):
+            # the kernels' path: local top-k with global ids, ONE RCCL all-gather, device merge (ShardedFlatSearcher)
+            torch = self.ctx._torch
+            s = self._device_searcher(nq, k)
+            with torch.cuda.stream(s.stream):
+                q = torch.from_numpy(x).to(self.ctx.device, non_blocking=True)
+                D, I = s.search(q)
+                Dh, Ih = D.cpu(), I.cpu()
+            return Dh.numpy(), Ih.numpy()
+        D, I = self.local.search(x, k)
+        I = np.where(I >= 0, I + self.first_row, -1)
+        Da, Ia = self.ctx.all_gather(D), self.ctx.all_gather(I)
+        return merge_topk_host(Da, Ia, k, larger_is_better=self.metric_type == 0)
+
+    def reset(self):
+        self.local.reset()
+        self._ntotal, self.first_row = 0, 0
+
+    def reconstruct_n(self, n0=0, ni=None):
+        raise NotImplementedError("a row-sharded index is searched and appended to; write_index / save() need the "
+                                  "whole matrix: save from an unsharded store")
+
+
+class ShardedBM25:
+    """rank_bm25.BM25Okapi surface (get_scores, top_k, k1, b, idf, avgdl, corpus_size) over one rank's block of
+    the chunk rows: the LOCAL index holds this rank's postings with the statistics (idf, avgdl) of the WHOLE corpus
+    (bm25.BM25Okapi(..., shard=(first, count)))."""
+
+    def __init__(self, local, first_row, n_total, ctx):
+        self.local, self.first_row, self.corpus_size, self.ctx = local, int(first_row), int(n_total), ctx
+        self.k1, self.b, self.epsilon = local.k1, local.b, local.epsilon
+        self.idf, self.avgdl, self.average_idf = local.idf, local.avgdl, local.average_idf
+
+    def get_scores(self, query):
+        import numpy as np
+        per = (self.corpus_size + self.ctx.world - 1) // self.ctx.world
+        mine = np.zeros(per, dtype=np.float64)
+        s = self.local.get_scores(query) if self.local.n_local else np.zeros(0)
+        mine[:len(s)] = s
+        allr = self.ctx.all_gather(mine)
+        return np.concatenate([allr[r][:cnt] for r, (_lo, cnt) in enumerate(shard_bounds(self.corpus_size, self.ctx.world))])
+
+    def top_k(self, query, k):
+        import numpy as np
+        k = min(int(k), self.corpus_size)
+        if k <= 0:
+            return np.empty(0, np.int64), np.empty(0, np.float64)
+        D = np.full((1, k), -np.inf, dtype=np.float64)
+        I = np.full((1, k), -1, dtype=np.int64)
+        if self.local.n_local:
+            ids, sc = self.local.top_k(query, k)
+            D[0, :len(ids)] = sc
+            I[0, :len(ids)] = np.asarray(ids, dtype=np.int64) + self.first_row
+        Dm, Im = merge_topk_host(self.ctx.all_gather(D), self.ctx.all_gather(I), k)
+        return Im[0], Dm[0]
+
+
+class ShardedTfidfScorer:
+    """tfidf.TfidfScorer surface (scores, top_k, query) over one rank's block of the document rows."""
+
+    def __init__(self, local, first_row, n_docs, ctx, vectorizer):
+        self.local, self.first_row, self.n_docs, self.ctx, self.vectorizer = local, int(first_row), int(n_docs), ctx, vectorizer
+
+    def _n_local(self):
+        return self.local.n_docs if self.local is not None else 0
+
+    def scores(self, query):
+        import numpy as np
+        per = (self.n_docs + self.ctx.world - 1) // self.ctx.world
+        mine = np.zeros(per, dtype=np.float64)
+        if self._n_local():
+            s = self.local.scores(query)
+            mine[:len(s)] = s
+        allr = self.ctx.all_gather(mine)
+        return np.concatenate([allr[r][:cnt] for r, (_lo, cnt) in enumerate(shard_bounds(self.n_docs, self.ctx.world))])
+
+    def top_k(self, query, k):
+        return self.query(query, k, [])[:2]
+
+    def query(self, query, k, doc_indices):
+        """(top_idx, top_scores, ranks, scores) as TfidfScorer.query: the first k documents of the stable
+        descending ranking of ALL documents, and rank / score of the given (global) document rows.  A document's
+        rank is the sum over the shards of the rows standing ahead of its (score, row) pair (rag_csc_count_ahead)."""
+        import numpy as np
+        k = min(int(k), self.n_docs)
+        rows = np.asarray(doc_indices, dtype=np.int64).reshape(-1)
+        D = np.full((1, max(k, 1)), -np.inf, dtype=np.float64)
+        I = np.full((1, max(k, 1)), -1, dtype=np.int64)
+        nl = self._n_local()
+        if nl:
+            ids, sc = self.local.top_k(query, min(max(k, 1), nl))      # (leaves the score vector on the device)
+            D[0, :len(ids)] = sc
+            I[0, :len(ids)] = np.asarray(ids, dtype=np.int64) + self.first_row
+        Dm, Im = merge_topk_host(self.ctx.all_gather(D), self.ctx.all_gather(I), max(k, 1))
+        top_idx, top_sc = Im[0][:k], Dm[0][:k]
+        if len(rows) == 0:
+            return top_idx, top_sc, [], []
+        # scores of the queried rows: each from its owner (one exchange), then every shard counts what it holds
+        # ahead of every pair (one more)
+        mine = (rows >= self.first_row) & (rows < self.first_row + nl)
+        sc = np.zeros(len(rows), dtype=np.float64)
+        if mine.any():
+            sc[mine] = self.local.gather(rows[mine] - self.first_row)
+        owned = self.ctx.all_gather(np.stack([sc, mine.astype(np.float64)]))
+        scores = (owned[:, 0, :] * owned[:, 1, :]).sum(axis=0)
+        cnt = self.local.count_ahead(scores, rows - self.first_row) if nl else np.zeros(len(rows), dtype=np.int64)
+        ranks = self.ctx.all_reduce_sum(np.asarray(cnt, dtype=np.int64))
+        return top_idx, top_sc, ranks, scores

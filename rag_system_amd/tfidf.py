@@ -23,11 +23,17 @@ from . import bm25 as _bm25
 
 
 class TfidfScorer:
-    def __init__(self, vectorizer, matrix):
+    def __init__(self, vectorizer, matrix, shard=None):
+        """shard=(first, count) (rag_system_amd.sharded): only the document rows [first, first + count) of
+        `matrix` are uploaded, as local rows 0 .. count-1 (row normalisation is per row: the block's rows are
+        those of the whole matrix)."""
         from sklearn.preprocessing import normalize
         self.vectorizer = vectorizer
+        matrix = matrix.tocsr()
+        if shard is not None:
+            matrix = matrix[int(shard[0]):int(shard[0]) + int(shard[1])]
         self.n_docs, self.n_terms = matrix.shape
-        mn = normalize(matrix.tocsr(), copy=True)   # what cosine_similarity does to Y
+        mn = normalize(matrix, copy=True)   # what cosine_similarity does to Y
         csc = mn.tocsc()
         csc.sort_indices()
         self._csc = _bm25.make_csc(self.n_terms, self.n_docs, csc.indptr.astype(np.int64),
@@ -112,6 +118,11 @@ class TfidfScorer:
     def gather(self, doc_indices):
         """Scores of the given documents from the LAST scores()/top_k() call."""
         return self._csc.gather(doc_indices)
+
+    def count_ahead(self, keys, ids):
+        """Per (score, id) pair: how many documents of the LAST scores()/top_k() call stand ahead of it (ids in
+        this scorer's row numbering, possibly outside it: rag_csc_count_ahead)."""
+        return self._csc.count_ahead(keys, ids)
 
     def ranks_from_row(self, indices, data, k, doc_indices):
         """(top_idx, top_scores, ranks): top_k_from_row(k) + ranks(doc_indices) in one engine call."""

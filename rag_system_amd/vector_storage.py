@@ -220,9 +220,53 @@ class VectorStorage:
             return None
         key = (id(self.tfidf_vectorizer), id(self.tfidf_index))
         if self._tfidf_scorer is None or self._tfidf_scorer_key != key:
-            self._tfidf_scorer = TfidfScorer(self.tfidf_vectorizer, self.tfidf_index)
+            ctx = getattr(self, "_shard_ctx", None)
+            if ctx is not None:     # this rank's block of the document rows (rag_system_amd.sharded)
+                from .sharded import ShardedTfidfScorer, shard_bounds
+                n_docs = self.tfidf_index.shape[0]
+                lo, cnt = shard_bounds(n_docs, ctx.world)[ctx.rank]
+                local = TfidfScorer(self.tfidf_vectorizer, self.tfidf_index, shard=(lo, cnt)) if cnt else None
+                self._tfidf_scorer = ShardedTfidfScorer(local, lo, n_docs, ctx, self.tfidf_vectorizer)
+            else:
+                self._tfidf_scorer = TfidfScorer(self.tfidf_vectorizer, self.tfidf_index)
             self._tfidf_scorer_key = key
         return self._tfidf_scorer
+
+    # ---- row sharding over the GPUs of one node (one process per GPU) ---------------------------
+
+    def shard(self, ctx=None, dense_rows=None):
+        """Turn this store -- complete host metadata, as every rank loads or builds it -- into ONE RANK'S PART of a
+        row-sharded store: the dense index keeps the contiguous row block of this rank (global ids = block start
+        + local row), the BM25 and TF-IDF indices the postings of this rank's block of chunk / document rows, with
+        the statistics (idf, avgdl) of the whole corpus.  search / search_bm25 / the TF-IDF scorer then exchange
+        their per-rank top lists with one all-gather and merge them: every rank returns what the unsharded store
+        returns (tests/test_sharded_gloo.py).  SPMD: every rank calls the same methods with the same arguments.
+        ctx: rag_system_amd.sharded.ShardContext (default: torch.distributed's default group).
+        A sharded store is searched and appended to; save() needs the whole matrix and is refused."""
+        from .sharded import ShardContext, ShardedBM25, ShardedIndexFlat, shard_bounds
+        ctx = ctx or ShardContext()
+        if getattr(self.index, "sharded", False):
+            raise ValueError("this store is sharded already")
+        n = self.index.ntotal if dense_rows is None else dense_rows[1]
+        lo, cnt = shard_bounds(n, ctx.world)[ctx.rank]
+        if dense_rows is None:      # the index holds every row: keep this rank's block
+            local = faiss.IndexFlat(self.embedding_dim, self.index.metric_type)
+            if cnt:
+                local.add(self.index.reconstruct_n(lo, cnt))
+        else:                       # load(shard=...): only the block was read from index.faiss
+            local = self.index
+        if self._dense_prefilter:
+            local.set_prefilter(True)
+        self.index = ShardedIndexFlat(local, lo, n, ctx)
+        self._shard_ctx = ctx
+        if self.bm25 is not None:
+            nb = len(self.bm25_corpus)
+            blo, bcnt = shard_bounds(nb, ctx.world)[ctx.rank]
+            local_bm = BM25Okapi(self.bm25_corpus, k1=self.bm25.k1, b=self.bm25.b, shard=(blo, bcnt))
+            self.bm25 = ShardedBM25(local_bm, blo, nb, ctx)
+        self._tfidf_scorer = None       # rebuilt sharded by get_tfidf_scorer
+        self._tfidf_scorer_key = None
+        return self
 
     def hybrid_doc_tables(self, scorer):
         """Side tables of rag_hybrid_rrf_mmr's MMR stage for the current indices, uploaded once (SURVEY 8(f) f4
@@ -281,6 +325,9 @@ class VectorStorage:
         holds in HBM -- the ones add_vector received -- and only rebuilds the BM25 / TF-IDF indices; the files
         have the same layout, the dense rows differ from a re-encoded save only where the reference's own
         quirk makes them differ (normalised adds vs raw model outputs)."""
+        if getattr(self.index, "sharded", False):
+            raise ValueError("a row-sharded store cannot be saved (each rank holds a block of the rows): save from an "
+                             "unsharded store")
         if reencode or self.index.ntotal != len(self.chunks_data):
             self.rebuild_all_indices(embedding_manager)
         else:
@@ -314,7 +361,7 @@ class VectorStorage:
         return paths["faiss"], paths["bm25"], paths["tfidf"], paths["meta"]
 
     @classmethod
-    def load(cls, storage_dir, bm25_params="reference"):
+    def load(cls, storage_dir, bm25_params="reference", shard=None):
         """Stores are the caller's own files (written by save() here or by the reference).
 
         bm25_params: the reference scores a FRESH store with Config's k1 = 1.0, b = 0.65
@@ -341,7 +388,16 @@ class VectorStorage:
         storage.chunks_data = meta.get("chunks_data", [])
         storage.documents = meta.get("documents", {})
         storage.signatures = meta.get("signatures", {})
-        storage.index = faiss.read_index(paths["faiss"])
+        ctx = None
+        if shard is not None and shard is not False:
+            # shard=True / a ShardContext: this rank reads only ITS block of index.faiss (sharded below)
+            from .sharded import ShardContext, shard_bounds
+            ctx = shard if isinstance(shard, ShardContext) else ShardContext()
+            n_file = faiss.read_index(paths["faiss"], 0, 0).file_ntotal
+            lo, cnt = shard_bounds(n_file, ctx.world)[ctx.rank]
+            storage.index = faiss.read_index(paths["faiss"], lo, cnt)
+        else:
+            storage.index = faiss.read_index(paths["faiss"])
         if "bm25" in indices_present and os.path.exists(paths["bm25"]):
             with open(paths["bm25"], "rb") as f:
                 data = safe_pickle.load_plain(f, "index_bm25.pkl")
@@ -357,6 +413,8 @@ class VectorStorage:
             storage.tfidf_index = data["tfidf_index"]
             storage.tfidf_vectorizer = data["tfidf_vectorizer"]
             storage.tfidf_doc_ids = data["tfidf_doc_ids"]
+        if ctx is not None:
+            storage.shard(ctx, dense_rows=(lo, n_file))
         return storage
 
 
@@ -391,8 +449,20 @@ class VectorStorageManager:
         storage.set_chunk_params(embedding_manager.chunk_size, embedding_manager.overlap)
         storage.save(os.path.join(base_dir, name), embedding_manager, reencode=reencode)
 
-    def load_storage(self, name, base_dir, bm25_params="reference"):
-        storage = VectorStorage.load(os.path.join(base_dir, name), bm25_params=bm25_params)
+    def load_storage(self, name, base_dir, bm25_params="reference", shard=None):
+        """shard (not in the reference): None = Config.ENGINE_SHARD ("auto": shard over torch.distributed's ranks
+        when a process group with more than one rank is initialised), True / a ShardContext = shard, False = not."""
+        if shard is None:
+            shard = Config.ENGINE_SHARD
+        if shard == "auto":
+            shard = False
+            try:
+                import sys
+                dist = sys.modules.get("torch.distributed")     # never imports torch by itself
+                shard = bool(dist is not None and dist.is_initialized() and dist.get_world_size() > 1)
+            except Exception:
+                shard = False
+        storage = VectorStorage.load(os.path.join(base_dir, name), bm25_params=bm25_params, shard=shard or None)
         self.storages[name] = storage
         return storage
 

@@ -34,6 +34,21 @@ class OracleFlatBackend:
         return self._rows[first:first + n].copy()
 
 
+class OracleFlatBackendF32(OracleFlatBackend):
+    """Orders like the GPU: by the float32 score it returns, lower id first among equal float32 scores (the plain
+    oracle backend orders by the float64 score, which can separate two rows whose float32 scores are equal; a
+    row-sharded search merges float32 lists and cannot know)."""
+
+    def search(self, q, k):
+        D, I = super().search(q, k)
+        for r in range(len(D)):
+            pad = I[r] < 0
+            key = -D[r] if self.metric == 0 else D[r]
+            order = np.lexsort((I[r], key, pad))
+            D[r], I[r] = D[r][order], I[r][order]
+        return D, I
+
+
 class OracleCsc:
     def __init__(self, n_terms, n_rows, indptr, rows, vals):
         self.n_terms, self.n_rows = n_terms, n_rows
@@ -77,6 +92,10 @@ class OracleCsc:
 
     def gather(self, rows):
         return self._last[np.asarray(rows, np.int64)]
+
+    def count_ahead(self, keys, ids):
+        s, j = self._last, np.arange(self.n_rows)
+        return np.array([int(((s > k) | ((s == k) & (j < i))).sum()) for k, i in zip(keys, ids)], dtype=np.int64)
 
 
 def _rrf(ids, lens, k):

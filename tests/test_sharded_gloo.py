@@ -107,3 +107,96 @@ def test_fake_shards_1_2_4_8_way_identical(metric):
         Il.append(np.where(I >= 0, I + lo, -1))
     Dm, Im = od.topk_merge(metric, np.stack(Dl), np.stack(Il))
     assert np.array_equal(Im, Iw) and np.array_equal(Dm, Dw)
+
+
+# ---- sharding behind the drop-in API: VectorStorage.shard() / load(shard=...) -----------------------------------
+
+def _store_worker(rank, world, port, tmpdir, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        warnings.simplefilter("ignore")
+        from _data import zipf_queries
+        from _oracle_backends import OracleFlatBackendF32, oracle_backends
+        from test_host_logic import STRATEGIES, _build_store
+        from rag_system_amd import faiss_compat
+        from rag_system_amd.search_engine import SearchEngine
+        from rag_system_amd.sharded import ShardContext
+        from rag_system_amd.vector_storage import VectorStorageManager
+        with oracle_backends():
+            faiss_compat.set_backend_factory(OracleFlatBackendF32)     # float32 ties by id, like the kernels
+            # every rank builds the same store (SPMD), keeps a whole copy as the reference and shards the other
+            mgr, whole, em = _build_store(n_docs=50, seed=5, dim=48)
+            _m2, store, _em = _build_store(n_docs=50, seed=5, dim=48)
+            ctx = ShardContext()
+            assert (ctx.rank, ctx.world) == (rank, world)
+            store.shard(ctx)
+            n = len(whole.chunks_data)
+            assert store.index.ntotal == whole.index.ntotal == n and store.index.local.ntotal < n
+            assert store.bm25.local.n_local < len(whole.bm25_corpus) and store.bm25.idf == whole.bm25.idf
+            queries = [" ".join(t) for t in zipf_queries(5, 400, seed=9)] + ["zzzz qqqq", whole.chunks_data[5]["chunk"][:80]]
+            # the three searches under the strategies: dense top-k, BM25 top-k and scores, TF-IDF top-k / ranks / scores
+            for q in queries:
+                qv = em.embed_query(q)
+                for k in (1, 7, 40, n + 5):                       # incl. k > ntotal (padding: the last chunk quirk)
+                    assert store.search(qv, k) == whole.search(qv, k), (rank, q, k)
+                    assert store.search_bm25(q, k) == whole.search_bm25(q, k), (rank, q, k)
+                from rag_system_amd.text import word_tokenize
+                toks = word_tokenize(q.lower())
+                assert store.bm25.get_scores(toks).tobytes() == whole.bm25.get_scores(toks).tobytes()
+                ts, tw = store.get_tfidf_scorer(), whole.get_tfidf_scorer()
+                rows = [0, 3, 7, len(whole.tfidf_doc_ids) - 1, 3]    # rows of both shards, one of them twice
+                a, b = ts.query(q, 9, rows), tw.query(q, 9, rows)
+                for x, y in zip(a, b):
+                    assert np.asarray(x).tolist() == np.asarray(y).tolist(), (rank, q)
+                assert ts.scores(q).tobytes() == tw.scores(q).tobytes()
+            # every strategy through SearchEngine: the sharded store answers like the whole one
+            es, ew = SearchEngine(store, em), SearchEngine(whole, em)
+            for q in queries[:4]:
+                for strategy, mode in STRATEGIES:
+                    for kw in ({}, {"use_mmr": True, "mmr_reuse_index_vectors": True}):
+                        got = es.search_with_strategy(q, strategy, 6, mode, **kw)
+                        exp = ew.search_with_strategy(q, strategy, 6, mode, **kw)
+                        assert got == exp, (rank, q, strategy, mode, kw)
+            # rows added later go to the last rank; ids stay those of the unsharded store
+            for st_ in (store, whole):
+                st_.add_vector(em.embed_query("fresh words added later"), "late", "fresh words added later", "late.txt")
+            qv = em.embed_query("fresh words added later")
+            assert store.search(qv, 3) == whole.search(qv, 3) and store.search(qv, 1)[0]["doc_id"] == "late"
+            with pytest.raises(ValueError):
+                store.save(os.path.join(tmpdir, "nope"), em)
+            # load(shard=...): only this rank's rows are read from index.faiss
+            if rank == 0:
+                mgr.save_storage("s", tmpdir, em, reencode=False)
+            dist.barrier()
+            loaded = VectorStorageManager().load_storage("s", tmpdir, bm25_params="config", shard=True)
+            ref = VectorStorageManager().load_storage("s", tmpdir, bm25_params="config", shard=False)
+            assert loaded.index.sharded and loaded.index.local.ntotal < ref.index.ntotal == loaded.index.ntotal, (
+                loaded.index.local.ntotal, ref.index.ntotal, loaded.index.ntotal)
+            auto = VectorStorageManager().load_storage("s", tmpdir)      # Config.ENGINE_SHARD = "auto": a group exists
+            assert getattr(auto.index, "sharded", False)
+            el, er = SearchEngine(loaded, em), SearchEngine(ref, em)
+            for q in queries[:3]:
+                for strategy, mode in STRATEGIES:
+                    assert el.search_with_strategy(q, strategy, 5, mode) == er.search_with_strategy(q, strategy, 5, mode)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_vector_storage_answers_like_the_whole_store(world, tmp_path):
+    """the multi-GPU path behind VectorStorage / SearchEngine, dense AND sparse: every rank of
+    a gloo group holds a block of the dense rows and of the BM25 / TF-IDF postings (whole-corpus statistics) and
+    returns, for every search and every strategy, exactly what the unsharded store returns -- ties across the
+    shard border (the duplicated document of _build_store), k beyond the corpus, rows added after sharding."""
+    port = 29500 + (os.getpid() % 2000) + 10 + world
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_store_worker, args=(world, port, str(tmp_path), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}

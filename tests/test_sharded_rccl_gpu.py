@@ -65,3 +65,54 @@ def test_one_rank_rccl_exchange_equals_local_search(engine):
             assert t["scan_ms"] > 0 and t["allgather_ms"] >= 0 and t["merge_ms"] > 0
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_sharded_vector_storage_over_a_one_rank_rccl_group(engine, tmp_path):
+    """VectorStorage.shard() / load(shard=True) on the HIP engine with RCCL as the transport (one rank, every
+    exchange forced through the collectives): dense search through rag_flat_search_dev + all_gather_into_tensor
+    + rag_topk_merge_strided_dev, BM25 / TF-IDF through their top-k + rag_csc_count_ahead + all-gather /
+    all-reduce of device tensors -- results equal to the unsharded store's, every strategy."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _data import zipf_queries
+    from test_host_logic import STRATEGIES, _build_store
+    from rag_system_amd.search_engine import SearchEngine
+    from rag_system_amd.sharded import ShardContext
+    from rag_system_amd.vector_storage import VectorStorageManager
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        mgr, whole, em = _build_store(n_docs=120, seed=31, dim=96)
+        _m, store, _e = _build_store(n_docs=120, seed=31, dim=96)
+        ctx = ShardContext(force_exchange=True)
+        assert ctx.device.type == "cuda" and ctx.world == 1
+        store.shard(ctx)
+        queries = [" ".join(t) for t in zipf_queries(5, 400, seed=3)] + [whole.chunks_data[7]["chunk"][:60]]
+        es, ew = SearchEngine(store, em), SearchEngine(whole, em)
+        for q in queries:
+            qv = em.embed_query(q)
+            for k in (1, 10, 40):
+                assert store.search(qv, k) == whole.search(qv, k)
+                assert store.search_bm25(q, k) == whole.search_bm25(q, k)
+            rows = [0, 5, 9, 5]
+            a, b = store.get_tfidf_scorer().query(q, 12, rows), whole.get_tfidf_scorer().query(q, 12, rows)
+            for x, y in zip(a, b):
+                assert np.asarray(x).tolist() == np.asarray(y).tolist()
+            for strategy, mode in STRATEGIES:
+                assert es.search_with_strategy(q, strategy, 6, mode) == ew.search_with_strategy(q, strategy, 6, mode)
+        mgr.save_storage("s", str(tmp_path), em, reencode=False)
+        loaded = VectorStorageManager().load_storage("s", str(tmp_path), bm25_params="config", shard=ctx)
+        assert loaded.index.sharded
+        el = SearchEngine(loaded, em)
+        for q in queries[:3]:
+            assert el.search_with_strategy(q, "rrf", 5) == ew.search_with_strategy(q, "rrf", 5)
+    finally:
+        dist.destroy_process_group()

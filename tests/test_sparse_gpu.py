@@ -411,3 +411,29 @@ def test_topk_threshold_path_matches_stable_sort(engine):
         assert I.tolist() == order[:100].tolist()
     finally:
         lib.rag_set_option(b"sparse_topk_lists", 0)
+
+
+def test_count_ahead_of_arbitrary_pairs(engine):
+    """rag_csc_count_ahead: rows of the last score vector ahead of (score, id) pairs that need not be rows of the
+    index -- what a row-sharded TF-IDF / BM25 index sums over its shards to rank a document.  Against numpy, with
+    exact score ties, ids below 0 and beyond n (another shard's rows), own rows (= rag_csc_ranks), repeated pairs,
+    and more pairs than one launch takes."""
+    from scipy.sparse import random as sprandom
+    from rag_system_amd.tfidf import TfidfScorer
+    rng = np.random.default_rng(17)
+    n, V = 30_000, 500
+    M = sprandom(n, V, density=0.02, format="csr", random_state=3, dtype=np.float64)
+    M.data = np.round(M.data * 4) / 4 + 0.25
+    ts = TfidfScorer(None, M)
+    s = ts.scores_from_row(np.array([3, 17, 40], dtype=np.int32), np.array([1.0, 2.0, 1.0]))
+    j = np.arange(n)
+    own = rng.choice(n, 300, replace=False)
+    keys = np.concatenate([s[own], s[rng.choice(n, 900)], np.array([0.0, -1.0, 10.0, s.max()])])
+    ids = np.concatenate([own, rng.integers(-50_000, 80_000, 900), np.array([-5, 10, n + 7, -1])]).astype(np.int64)
+    keys = np.concatenate([keys, keys[:5]])
+    ids = np.concatenate([ids, ids[:5]])
+    got = ts.count_ahead(keys, ids)
+    exp = np.array([int(((s > k) | ((s == k) & (j < i))).sum()) for k, i in zip(keys, ids)])
+    assert got.tolist() == exp.tolist()
+    assert got[:300].tolist() == ts.ranks(own).tolist()
+    assert len(keys) > 1024
