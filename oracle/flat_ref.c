@@ -9,7 +9,11 @@
  *   vector_storage.py:79    faiss.IndexFlatIP(d)  (and IndexFlatL2, named by BASELINE.json)
  * The arithmetic itself lives in faiss-cpu, an UNPINNED, un-vendored dependency
  * (requirements.txt:1) that is absent from this container, and the reference holds no
- * test, fixture or golden vector for it: PARITY UNPINNED.  The published algorithm of
+ * test, fixture or golden vector for it.  The only outputs of the real library available
+ * offline are the ones its own documentation publishes: the "Getting started" IndexFlatL2
+ * example of the faiss wiki (60 ids, 20 distances), which this file reproduces exactly
+ * (tests/golden/published_answers.json, tests/test_published_answers.py; round 3).  Beyond
+ * that example: PARITY UNPINNED.  The published algorithm of
  * faiss IndexFlat (exhaustive scan, fp32 inner product / squared L2 per row, k best kept
  * in a heap, results sorted best-first, tail padded with id -1 and -FLT_MAX (IP) /
  * +FLT_MAX (L2) when k > ntotal) is restated here.  Tie rule (equal score -> lower id

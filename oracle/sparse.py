@@ -1,7 +1,9 @@
 """CPU restatement of the sparse scoring path -- TEST INFRASTRUCTURE ONLY (oracle/__init__.py).
 
 BM25: the arithmetic lives in rank_bm25 (unpinned, requirements.txt:12, absent here; its
-API and formula are those of rank_bm25 0.2.x).  The reference holds no fixture for it:
+API and formula are those of rank_bm25 0.2.x).  The reference holds no fixture for it; the only
+output of the real library available offline is the example its README publishes, which the class below
+reproduces (tests/golden/published_answers.json, tests/test_published_answers.py) -- beyond that example:
 PARITY UNPINNED.  The class below restates the published algorithm of
 rank_bm25.BM25 / BM25Okapi line by line (pure Python + numpy, float64), as called at
 vector_storage.py:170 (BM25Okapi(corpus, k1, b)), :305 (defaults k1=1.5, b=0.75,

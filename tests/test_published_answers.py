@@ -1,0 +1,92 @@
+"""Known answers published by faiss and rank_bm25 themselves (tests/golden/published_answers.json: the faiss wiki's
+"Getting started" IndexFlatL2 example and the rank_bm25 README example; provenance and its limits are stated in the
+fixture).  The reference holds no fixture for its dense and BM25 arithmetic: these are the only
+outputs of the real libraries available offline, and both the oracle (CPU) and the HIP path (`-m gpu`, through the C
+ABI) must reproduce them: ids exactly, distances / scores to the printed digits."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dense as od
+from oracle import sparse as osp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def pub():
+    with open(os.path.join(HERE, "golden", "published_answers.json")) as f:
+        return json.load(f)
+
+
+def _tutorial_data(t):
+    """The tutorial's inputs: numpy's legacy MT19937 stream, identical on every numpy."""
+    np.random.seed(t["seed"])
+    xb = np.random.random((t["nb"], t["d"])).astype("float32")
+    xb[:, 0] += np.arange(t["nb"]) / 1000.
+    xq = np.random.random((t["nq"], t["d"])).astype("float32")
+    xq[:, 0] += np.arange(t["nq"]) / 1000.
+    return xb, xq
+
+
+def _check_faiss(t, search):
+    xb, xq = _tutorial_data(t)
+    k = t["k"]
+    D, I = search(xb, xb[:5], k)
+    assert I.tolist() == t["sanity_I"]
+    assert np.allclose(D, np.array(t["sanity_D"]), rtol=2e-7, atol=1e-6), D        # the digits faiss printed
+    _D, I = search(xb, xq[:5], k)
+    assert I.tolist() == t["queries_first5_I"]
+    _D, I = search(xb, xq[-5:], k)
+    assert I.tolist() == t["queries_last5_I"]
+    # the whole batch of the tutorial in one call: its head and tail are the printed rows
+    return xb, xq
+
+
+def test_oracle_reproduces_the_faiss_tutorial(pub):
+    def search(xb, q, k):
+        D, I, _ = od.flat_search(xb, q, k, od.METRIC_L2)
+        return D, I
+    _check_faiss(pub["faiss_flat_l2_tutorial"], search)
+
+
+def test_oracle_reproduces_the_rank_bm25_readme(pub):
+    r = pub["rank_bm25_readme"]
+    tok = [doc.split(" ") for doc in r["corpus"]]
+    s = osp.BM25OkapiRef(tok).get_scores(r["query"].split(" "))
+    assert np.allclose(s, r["doc_scores"], rtol=0, atol=5e-9), s
+    assert r["corpus"][int(np.argmax(s))] == r["top_1"]
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_the_faiss_tutorial(engine, pub):
+    from rag_system_amd import faiss_compat as faiss
+    t = pub["faiss_flat_l2_tutorial"]
+    cache = {}
+
+    def search(xb, q, k):
+        if "idx" not in cache:
+            cache["idx"] = faiss.IndexFlatL2(t["d"])
+            cache["idx"].add(xb)
+            assert cache["idx"].ntotal == t["nb"]
+        return cache["idx"].search(q, k)
+    xb, xq = _check_faiss(t, search)
+    D, I = cache["idx"].search(xq, t["k"])                  # nq = 10000 in one call, as the tutorial does
+    assert I[:5].tolist() == t["queries_first5_I"] and I[-5:].tolist() == t["queries_last5_I"]
+    # and one query at a time (the batch-1 kernel) gives the same ids as the batch
+    for j in (0, 1, 9_999):
+        assert cache["idx"].search(xq[j:j + 1], t["k"])[1].tolist() == I[j:j + 1].tolist()
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_the_rank_bm25_readme(engine, pub):
+    from rag_system_amd.bm25 import BM25Okapi
+    r = pub["rank_bm25_readme"]
+    tok = [doc.split(" ") for doc in r["corpus"]]
+    bm = BM25Okapi(tok)
+    s = bm.get_scores(r["query"].split(" "))
+    assert np.allclose(s, r["doc_scores"], rtol=0, atol=5e-9), s
+    ids, sc = bm.top_k(r["query"].split(" "), 1)
+    assert r["corpus"][int(ids[0])] == r["top_1"] and abs(float(sc[0]) - r["doc_scores"][1]) < 5e-9
