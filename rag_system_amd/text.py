@@ -2,8 +2,9 @@
 
 word_tokenize: the reference tokenises BM25 chunks and queries with nltk.word_tokenize
 (vector_storage.py:162,177).  nltk (and its punkt data, fetched from the network at import in
-the reference) is an optional dependency here: when importable it is used, otherwise a regex
-tokenizer that splits words from punctuation the same way for plain prose.  Synthetic
+the reference) is an optional dependency here: when importable it is used, otherwise the Penn
+Treebank splitting rules it applies are restated as regular expressions (without punkt's sentence
+splitting).  Synthetic
 benchmarks use integer term ids, so tokenisation is outside every measured path.
 
 HashingEmbeddingManager: a deterministic, model-free stand-in for the reference's
@@ -19,18 +20,42 @@ import numpy as np
 
 import warnings
 
-_TOKEN_RE = re.compile(r"\w+|[^\w\s]", re.UNICODE)
-
 NLTK = "nltk.word_tokenize"
-FALLBACK = "regex-fallback"
+FALLBACK = "treebank-regex-fallback"
+
+# The Penn Treebank word-splitting rules nltk.word_tokenize applies to each sentence (nltk.tokenize.treebank,
+# restated from its published rule list): quotes to `` / '', commas and colons split unless inside numbers, the
+# period that ends the text, ; @ # $ % & ? ! brackets and -- set apart, contractions ('s 'm 'd 'll 're 've n't)
+# split off.  What is NOT reproduced is the punkt sentence splitter that runs before it (absent with nltk): a
+# period that ends a sentence in the MIDDLE of a text stays attached to its word here ("york." rather than
+# "york", "."), as it does in nltk's own TreebankWordTokenizer.  Reproduces the examples nltk documents
+# (tests/test_oracle_cpu.py); BM25 text parity with stores tokenised by the real nltk stays "parity unpinned".
+_TB_RULES = [(re.compile(p), r) for p, r in (
+    (r'^\"', r"``"), (r"(``)", r" \1 "), (r"([ \(\[{<])(\"|\'{2})", r"\1 `` "),
+    (r"([:,])([^\d])", r" \1 \2"), (r"([:,])$", r" \1 "), (r"\.\.\.", r" ... "), (r"[;@#$%&]", r" \g<0> "),
+    (r"([^\.])(\.)([\]\)}>\"\']*)\s*$", r"\1 \2\3 "), (r"[?!]", r" \g<0> "), (r"([^'])' ", r"\1 ' "),
+    (r"[\]\[\(\)\{\}\<\>]", r" \g<0> "), (r"--", r" -- "))]
+_TB_RULES2 = [(re.compile(p), r) for p, r in (
+    (r'"', " '' "), (r"(\S)(\'\')", r"\1 \2 "), (r"([^' ])('[sS]|'[mM]|'[dD]|') ", r"\1 \2 "),
+    (r"([^' ])('ll|'LL|'re|'RE|'ve|'VE|n't|N'T) ", r"\1 \2 "))]
+
+
+def _treebank_tokenize(text):
+    for rx, rep in _TB_RULES:
+        text = rx.sub(rep, text)
+    text = " " + text + " "
+    for rx, rep in _TB_RULES2:
+        text = rx.sub(rep, text)
+    return text.split()
 _tokenizer = None   # (name, callable), resolved once
 
 
 def _resolve():
     """nltk.word_tokenize (punkt + treebank: what the reference uses, vector_storage.py:162,177) when nltk
     and its punkt data are usable, else the regex fallback -- decided ONCE per process, with one warning:
-    the two differ on contractions ("don't" -> do / n't against don / ' / t), ellipses, quotes and currency,
-    so BM25 scores of a store tokenised by one and queried with the other differ from the reference's.
+    the two agree on contractions, decimals, currency, quotes and brackets (the Treebank rules) and differ where
+    punkt would have split sentences (a period ending a sentence in mid-text stays on its word here), so BM25
+    scores of a store tokenised by one and queried with the other can differ from the reference's.
     BM25 TEXT parity is therefore 'parity unpinned' without nltk; the numeric parity tests use token lists."""
     global _tokenizer
     if _tokenizer is None:
@@ -42,7 +67,7 @@ def _resolve():
             warnings.warn("nltk (or its punkt data) is not available: BM25 text is tokenised by a regex fallback; "
                           "scores of stores tokenised by the reference's nltk.word_tokenize are not guaranteed "
                           "to match", RuntimeWarning, stacklevel=3)
-            _tokenizer = (FALLBACK, _TOKEN_RE.findall)
+            _tokenizer = (FALLBACK, _treebank_tokenize)
     return _tokenizer
 
 

@@ -214,3 +214,17 @@ def test_check_topk_rejects_a_repeated_id():
     pad = np.array([[5, -1, -1]])
     Dp = np.array([[3.0, -3.4028234663852886e38, -3.4028234663852886e38]])
     od.check_topk(Dp, pad, Dp, pad)      # pads repeat by construction
+
+
+def test_fallback_tokenizer_reproduces_nltks_documented_treebank_examples():
+    """The regex fallback for nltk.word_tokenize restates the Treebank rules: the three examples nltk's own
+    documentation gives for TreebankWordTokenizer come out as documented (no punkt: mid-text sentence periods
+    stay attached, as in that tokenizer)."""
+    from rag_system_amd.text import _treebank_tokenize as tb
+    assert tb("They'll save and invest more.") == ["They", "'ll", "save", "and", "invest", "more", "."]
+    assert tb("hi, my name can't hello,") == ["hi", ",", "my", "name", "ca", "n't", "hello", ","]
+    assert tb("Good muffins cost $3.88\nin New York.  Please buy me\ntwo of them.\nThanks.") == [
+        "Good", "muffins", "cost", "$", "3.88", "in", "New", "York.", "Please", "buy", "me", "two", "of", "them.",
+        "Thanks", "."]
+    assert tb('he said "no" (twice) -- really?') == ["he", "said", "``", "no", "''", "(", "twice", ")", "--", "really", "?"]
+    assert tb("") == [] and tb("plain words only") == ["plain", "words", "only"]
