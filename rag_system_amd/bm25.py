@@ -146,23 +146,31 @@ class _HipCsc:
 
     def hybrid_tail(self, flat_backend, dense_docs, bm25_docs, k_const, top_k, threshold, use_knee, q, lam, max_bytes):
         """rag_hybrid_rrf_mmr on this handle's begun query.  -> (fused_docs, fused_scores, n_kept, order or None),
-        or None when the engine does not serve the shape (the query stays begun: tfidf_query_end)."""
-        dd = np.ascontiguousarray(dense_docs, dtype=np.int64)
-        bd = np.ascontiguousarray(bm25_docs, dtype=np.int64)
-        fd = np.empty(max(top_k, 1), dtype=np.int64)
-        fs = np.empty(max(top_k, 1), dtype=np.float64)
-        order = np.empty(max(top_k, 1), dtype=np.int32)
-        nf, nk, done, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        or None when the engine does not serve the shape (the query stays begun: tfidf_query_end).
+        (Output buffers and their pointers are kept per handle: the caller holds the begun query, so calls on
+        one handle never overlap; a ctypes call with six fresh numpy pointers costs more than the kernel's launch.)"""
+        buf = getattr(self, "_tail_buf", None)
+        if buf is None or buf[0] < top_k:
+            cap = max(64, int(top_k))
+            fd, fs, order = np.empty(cap, np.int64), np.empty(cap, np.float64), np.empty(cap, np.int32)
+            ints = (C.c_int * 4)()
+            buf = self._tail_buf = (cap, fd, fs, order, ints, _lib.ptr(fd), _lib.ptr(fs), _lib.ptr(order),
+                                    C.cast(ints, C.c_void_p))
+        _cap, fd, fs, order, ints, pfd, pfs, porder, pints = buf
+        nd, nb = len(dense_docs), len(bm25_docs)
+        dd = (C.c_int64 * max(nd, 1))(*dense_docs)
+        bd = (C.c_int64 * max(nb, 1))(*bm25_docs)
         qv = None if q is None else np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+        base = pints.value
         rc = self._lib.rag_hybrid_rrf_mmr(
-            self._h, flat_backend._h if flat_backend is not None else None, len(dd), _lib.ptr(dd), len(bd), _lib.ptr(bd),
+            self._h, flat_backend._h if flat_backend is not None else None, nd, dd, nb, bd,
             float(k_const), int(top_k), float(threshold), 1 if use_knee else 0, _lib.ptr(qv), float(lam),
-            -1 if max_bytes is None else int(max_bytes), C.byref(nf), _lib.ptr(fd), _lib.ptr(fs), C.byref(nk),
-            C.byref(done), C.byref(ns), _lib.ptr(order))
+            -1 if max_bytes is None else int(max_bytes), base, pfd, pfs, base + 4, base + 8, base + 12, porder)
         if rc == _lib.RAG_ERR_UNSUPPORTED:
             return None
         _lib.check(rc, self._lib)
-        return (fd[:nf.value], fs[:nf.value], nk.value, order[:ns.value].tolist() if done.value else None)
+        nf, nk, done, ns = ints[0], ints[1], ints[2], ints[3]
+        return (fd[:nf].copy(), fs[:nf].copy(), nk, order[:ns].tolist() if done else None)
 
 
 _csc_factory = _HipCsc
