@@ -31,12 +31,12 @@ def _tutorial_data(t):
     return xb, xq
 
 
-def _check_faiss(t, search):
+def _check_faiss(t, search, rtol=2e-7, atol=1e-6):
     xb, xq = _tutorial_data(t)
     k = t["k"]
     D, I = search(xb, xb[:5], k)
     assert I.tolist() == t["sanity_I"]
-    assert np.allclose(D, np.array(t["sanity_D"]), rtol=2e-7, atol=1e-6), D        # the digits faiss printed
+    assert np.allclose(D, np.array(t["sanity_D"]), rtol=rtol, atol=atol), D        # the digits faiss printed
     _D, I = search(xb, xq[:5], k)
     assert I.tolist() == t["queries_first5_I"]
     _D, I = search(xb, xq[-5:], k)
@@ -72,7 +72,10 @@ def test_engine_reproduces_the_faiss_tutorial(engine, pub):
             cache["idx"].add(xb)
             assert cache["idx"].ntotal == t["nb"]
         return cache["idx"].search(q, k)
-    xb, xq = _check_faiss(t, search)
+    # the engine's L2 is ||x||^2 + ||q||^2 - 2<x, q> in fp32 (what faiss does from 20 queries on): with squared
+    # norms of ~21-10 000 here the distances carry that expansion's rounding -- 3.8e-6 where the tutorial prints
+    # an exact 0 for a row against itself -- inside north_star's 1e-5 relative of the operands' scale
+    xb, xq = _check_faiss(t, search, rtol=1e-5, atol=2e-5)
     D, I = cache["idx"].search(xq, t["k"])                  # nq = 10000 in one call, as the tutorial does
     assert I[:5].tolist() == t["queries_first5_I"] and I[-5:].tolist() == t["queries_last5_I"]
     # and one query at a time (the batch-1 kernel) gives the same ids as the batch
