@@ -583,8 +583,15 @@ class SearchEngine:
         if reuse_index_vectors:
             rows = self._chunk_rows(results)
             if rows is not None:
-                order = candidates.mmr_select_stored(self.vector_storage.index, rows, q, byte_lens, lambda_param,
-                                                     top_k, max_context_bytes)
+                index = self.vector_storage.index
+                if getattr(index, "sharded", False):
+                    # a row-sharded index: the candidates' rows come from the ranks that hold them (one all-gather
+                    # of C x d floats), then the same selection kernel on every rank
+                    order = candidates.mmr_select(index.gather_rows(rows), q, byte_lens, lambda_param, top_k,
+                                                  max_context_bytes)
+                else:
+                    order = candidates.mmr_select_stored(index, rows, q, byte_lens, lambda_param, top_k,
+                                                         max_context_bytes)
                 return [results[i] for i in order]
         emb = np.array(embedding_manager.model.encode(texts), dtype="float32")
         order = candidates.mmr_select(emb, q, byte_lens, lambda_param, top_k, max_context_bytes)
@@ -600,8 +607,8 @@ class SearchEngine:
                 table.setdefault((cd["doc_id"], cd["chunk"]), i)
             cache = (len(st.chunks_data), table)
             st._chunk_row_map = cache
-        if st.index.ntotal != len(st.chunks_data) or getattr(st.index, "sharded", False):
-            return None     # (a row-sharded index cannot gather arbitrary rows on one GPU: re-encode)
+        if st.index.ntotal != len(st.chunks_data):
+            return None
         rows = []
         for r in results:
             # a chunk hit, or a document entry whose text IS one stored chunk (a one-chunk document: the text

@@ -329,6 +329,19 @@ class ShardedIndexFlat:
         self.local.reset()
         self._ntotal, self.first_row = 0, 0
 
+    def gather_rows(self, rows):
+        """(len(rows), d) float32: the stored vectors of the given GLOBAL rows, each from the rank that holds it
+        (one all-gather of len(rows) x d floats) -- what MMR on stored rows needs for its handful of candidates."""
+        import numpy as np
+        rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        out = np.zeros((len(rows), self.d), dtype=np.float32)
+        mine = (rows >= self.first_row) & (rows < self.first_row + self.local.ntotal)
+        for j in np.nonzero(mine)[0]:
+            out[j] = self.local.reconstruct_n(int(rows[j] - self.first_row), 1)[0]
+        parts = self.ctx.all_gather(np.concatenate([out, mine[:, None].astype(np.float32)], axis=1))
+        owner = parts[:, :, -1].argmax(axis=0)
+        return np.ascontiguousarray(parts[owner, np.arange(len(rows)), :-1])
+
     def reconstruct_n(self, n0=0, ni=None):
         raise NotImplementedError("a row-sharded index is searched and appended to; write_index / save() need the "
                                   "whole matrix: save from an unsharded store")

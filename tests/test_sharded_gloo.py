@@ -162,6 +162,19 @@ def _store_worker(rank, world, port, tmpdir, ret):
                         got = es.search_with_strategy(q, strategy, 6, mode, **kw)
                         exp = ew.search_with_strategy(q, strategy, 6, mode, **kw)
                         assert got == exp, (rank, q, strategy, mode, kw)
+            # MMR on the stored rows: the candidates' vectors are gathered from their owners, no re-encoding
+            n_enc = []
+            real_encode = em.model.encode
+            em.model.encode = lambda texts, *a, **k: (n_enc.append(0 if isinstance(texts, str) else len(texts)),
+                                                      real_encode(texts, *a, **k))[1]
+            for q in queries[:3]:
+                got = es.search_with_strategy(q, "faiss", 8, "chunk", use_mmr=True, mmr_lambda=0.7, mmr_reuse_index_vectors=True)
+                assert got == ew.search_with_strategy(q, "faiss", 8, "chunk", use_mmr=True, mmr_lambda=0.7,
+                                                      mmr_reuse_index_vectors=True)
+            em.model.encode = real_encode
+            assert all(c <= 1 for c in n_enc), n_enc      # only single query texts were encoded
+            rows = [0, n - 1, n // 2, 3]
+            assert store.index.gather_rows(rows).tobytes() == whole.index.reconstruct_n()[rows].tobytes()
             # rows added later go to the last rank; ids stay those of the unsharded store
             for st_ in (store, whole):
                 st_.add_vector(em.embed_query("fresh words added later"), "late", "fresh words added later", "late.txt")
