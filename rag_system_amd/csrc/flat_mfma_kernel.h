@@ -524,6 +524,9 @@ constexpr int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 // no lists and is built for the 64-byte-row shapes (1-4, 9) and the 128-byte-row shapes 7, 8.
 }  // namespace mfma
 }  // namespace rag
+#ifndef RAG_PIPE_MFMA16
+#define RAG_PIPE_MFMA16 1
+#endif
 #include "flat_mfma_pipe.h"
 namespace rag {
 namespace mfma {
@@ -533,8 +536,10 @@ template <bool BF>
 int launch_pipe(const MfmaPlan& p, const Args& a) {
     const size_t smem = pipe_smem_need();
     const bool sample = a.thr_q == nullptr;
-    auto fn = a.metric == RAG_METRIC_IP ? (sample ? flat_pipe_kernel<RAG_METRIC_IP, BF, true> : flat_pipe_kernel<RAG_METRIC_IP, BF, false>)
-                                        : (sample ? flat_pipe_kernel<RAG_METRIC_L2, BF, true> : flat_pipe_kernel<RAG_METRIC_L2, BF, false>);
+    constexpr bool M16 = BF && RAG_PIPE_MFMA16 != 0;  // bfloat16 tiles as v_mfma_f32_16x16x32_bf16 (flat_mfma_pipe.h)
+    auto fn = a.metric == RAG_METRIC_IP
+                  ? (sample ? flat_pipe_kernel<RAG_METRIC_IP, BF, true, M16> : flat_pipe_kernel<RAG_METRIC_IP, BF, false, M16>)
+                  : (sample ? flat_pipe_kernel<RAG_METRIC_L2, BF, true, M16> : flat_pipe_kernel<RAG_METRIC_L2, BF, false, M16>);
     RAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     fn<<<(unsigned)(p.S * p.col_tiles), 512, smem, a.st>>>(a.X, a.n, a.ld, a.Qp, a.nq, p.S, p.col_tiles, a.cand_key,
                                                           a.cand_id, a.xnorm, a.qnorm, a.zero16, (long long)p.tile_step,

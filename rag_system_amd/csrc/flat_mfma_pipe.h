@@ -49,6 +49,15 @@
 // accumulator is the same as in flat_mfma_kernel, so the scores are bit-identical.
 #pragma once
 
+#include <type_traits>
+
+#ifndef RAG_PIPE_LEAN
+#define RAG_PIPE_LEAN 1
+#endif
+#ifndef RAG_PIPE_UNIFORM_WID
+#define RAG_PIPE_UNIFORM_WID 1
+#endif
+
 namespace rag {
 namespace mfma {
 
@@ -101,7 +110,7 @@ __device__ unsigned long long g_pipe_check[8];
 //   good, i.e. it is the j-th best sampled row unless two of the best j share a wave tile, which only
 //   lowers it.  No lists, no inserts: the pass costs what its tiles cost (it used to be the list-mode
 //   tile kernel, whose every list has to fill up first: 1.33 ms of C3's 17.2 for 1.6 % of the rows).
-template <int METRIC, bool BF, bool SAMPLE>
+template <int METRIC, bool BF, bool SAMPLE, bool M16>
 __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     const float* __restrict__ X, long long n, int ld, const float* __restrict__ Qp, int nq, int S, int col_tiles,
     float* __restrict__ cand_key, int* __restrict__ cand_id, const float* __restrict__ xnorm,
@@ -121,7 +130,12 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     float* Xs = reinterpret_cast<float*>(smem_raw);  // [NSX][BM][LDS_LD]
     float* Qs = Xs + NSX * STG;                      // [NSQ][BN][LDS_LD]   -- 160 KiB in all
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+#if RAG_PIPE_UNIFORM_WID
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations and M0 need no per-load readfirstlane
+#else
+    const int wid = tid >> 6;
+#endif
     const int li = lane & 31, lh = lane >> 5;
     const int wn = wid % WN, wm = wid / WN;
 
@@ -148,11 +162,14 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     const int nk = ld / BK;  // the plan admits only ld % BK == 0
     const int total = my_tiles * nk;
 
-    int my_q[NT];
-    float thr[NT], qn[NT];
+    static_assert(!M16 || BF, "the 16x16x32 shape exists for bfloat16 only");
+    constexpr int NQV = M16 ? 4 : NT;  // queries per lane: 16x16x32 tiles put query (lane & 15) of four 16-query blocks in a lane
+    const int l16 = lane & 15, lq = lane >> 4;
+    int my_q[NQV];
+    float thr[NQV], qn[NQV];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        my_q[u] = q0 + BNW * wn + 32 * u + li;
+    for (int u = 0; u < NQV; ++u) {
+        my_q[u] = M16 ? q0 + BNW * wn + 16 * u + l16 : q0 + BNW * wn + 32 * u + li;
         thr[u] = FLT_MAX;
         if (!SAMPLE) thr[u] = my_q[u] < nq ? thr_q[my_q[u]] : FLT_MAX;
         qn[u] = 0.f;
@@ -180,6 +197,82 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     // MFMAs); x_next() / q_next() move the cursor on after the stage's last instruction.
     // Past the end the loads still issue (zero source, into a ring buffer nobody reads any more) so
     // that the number of outstanding operations per iteration stays what the counted waits assume.
+#if RAG_PIPE_LEAN
+    // Lean cursors: everything a load needs besides its lane offset is scalar state that changes once per
+    // stage (x_next / q_next), so an x_ld / q_ld between two MFMAs is a few scalar adds, M0 and the load.
+    // Past the end nothing advances any more: the filler loads re-read the last stage (rows) or keep
+    // cycling through the query tile's stages -- valid addresses, into ring buffers nobody reads any more.
+    if (my_tiles == 0) return;  // uniform per workgroup, before any barrier
+    int px_tiles_left = my_tiles;
+    int px_row0 = s * tile_rows;
+    int px_ks = 0, px_buf = 0;
+    const char* px_src = Xb + (long long)px_row0 * ld * 4;  // row px_row0, K stage px_ks
+    // byte offset of this lane's 16 bytes from px_src, per instruction; in the last, partial row tile the rows
+    // past the end re-read the last row (masked in the epilogue)
+    unsigned xo[XQ];
+    auto set_xo = [&]() {
+#pragma unroll
+        for (int it = 0; it < XQ; ++it) {
+            int r = lrow + 64 * it;
+            r = px_row0 + r < nrows ? r : nrows - 1 - px_row0;
+            xo[it] = 4u * (unsigned)(r * ld + lcol);
+        }
+    };
+    set_xo();
+    int pq_ks = 0, pq_buf = 0;
+    const char* Qtb = reinterpret_cast<const char*>(Qt);
+    const char* pq_src = Qtb;
+    unsigned qo[QQ];  // this lane's 16 bytes of instruction `it`, from the stage's first byte
+#pragma unroll
+    for (int it = 0; it < QQ; ++it) {
+        qo[it] = 16u * (unsigned)((it * NWV + wid) * 64 + lane);
+    }
+    auto x_ld = [&](int it) {
+        float* dst = Xs + px_buf * STG + (it * NWV + wid) * 256;
+#if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
+        if (px_tiles_left < my_tiles) return;  // ablation: no loads after the first row tile
+#endif
+        RAG_GLDS(px_src + (unsigned long long)xo[it], dst, Xb, (long long)n * ld * 4, 1);
+    };
+    auto x_next = [&]() {
+        px_buf = px_buf + 1 == NSX ? 0 : px_buf + 1;
+        if (px_tiles_left > 0) {
+            if (++px_ks == nk) {
+                if (--px_tiles_left > 0) {
+                    px_ks = 0;
+                    px_row0 += tile_stride;
+                    px_src = Xb + (long long)px_row0 * ld * 4;
+                    if (px_row0 + BM > nrows) set_xo();  // at most once: the last tile
+                } else {
+                    --px_ks;  // stay on the last stage
+                }
+            } else {
+                px_src += BK * 4;
+            }
+        }
+    };
+    auto q_ld = [&](int it) {
+        float* dst = Qs + pq_buf * STG + (it * NWV + wid) * 256;
+#if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
+        return;
+#endif
+        // the stage is the LDS image itself: instruction `it` of this wave reads its 1 KiB in lane order
+        // (the empty asm keeps the zero extension in this block, where instruction selection folds it into the
+        // scalar-base + 32-bit-offset form of the load; hoisted out of the loop it becomes a 64-bit addition)
+        unsigned o = qo[it];
+        asm volatile("" : "+v"(o));
+        RAG_GLDS(pq_src + (unsigned long long)o, dst, Qtb, (long long)nk * STG * 4, 3);
+    };
+    auto q_next = [&]() {
+        pq_buf ^= 1;
+        if (++pq_ks == nk) {
+            pq_ks = 0;
+            pq_src = Qtb;
+        } else {
+            pq_src += STG * 4;
+        }
+    };
+#else
     int px_tiles_left = my_tiles;
     int px_row0 = s * tile_rows;
     int px_ks = 0, px_buf = 0;
@@ -228,13 +321,23 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         }
     };
 
-    f32x16 acc[MT][NT];
+#endif
+
+    f32x16 acc[MT][NT];      // 32x32 tiles (unused with M16)
+    f32x4 acc16[8][4];       // M16: 16x16 tiles, [row block of 16][query block of 16] (unused otherwise)
+    if (M16) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
+            for (int u = 0; u < 4; ++u) acc16[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    }
 
     // Fragment reads: inline assembly on purpose.  The compiler's own wait insertion treats the
     // loop-carried reads as "wait for everything" (lgkmcnt(0) in front of the MFMA batch that uses
@@ -308,6 +411,60 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
                     }
         }
     };
+    // M16: the same wave tile as 8 x 4 tiles of v_mfma_f32_16x16x32_bf16.  A K slice is 32 values (half a
+    // stage: 4 chunks of 16 bytes, chunk = 4 * slice + (lane >> 4)); lane l supplies row / query (l & 15) of
+    // every block of 16.  A slice's 32 MFMAs run as two batches of 16 (row blocks 0-3, then 4-7, against the
+    // same four query fragments), so that a batch again is 256 matrix cycles with the next batch's operands
+    // in flight: 4 reads (the other row half) or 8 (the next slice's first row half and its queries) per
+    // batch, 24 per stage as with the 32x32x16 shape.  Same LDS image and swizzle: rows r and r + 16 share
+    // swz(), and the sixteen lanes of each ds_read_b128 group touch sixteen different 16-byte bank groups.
+    const unsigned xfrag16 = xs_lds + 4u * (unsigned)((wm * BMW + l16) * LDS_LD);
+    const unsigned qfrag16 = qs_lds + 4u * (unsigned)((BNW * wn + l16) * LDS_LD);
+    unsigned pcb16[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) pcb16[kk] = 16u * (unsigned)((kk * 4 + lq) ^ swz<BK>(l16));
+    f32x4 pa_x[4], pb_x[4], pa_q[4], pb_q[4];
+    static_assert(16 * LDS_LD * 4 == 2048, "fragment offsets below");
+    auto read_x_lo = [&](int xbuf, int kk, f32x4(&ax)[4]) {  // row blocks 0-3 of slice kk
+        const unsigned xa = xfrag16 + (unsigned)xbuf * (STG * 4u) + pcb16[kk];
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(ax[0]) : "v"(xa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=&v"(ax[1]) : "v"(xa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=&v"(ax[2]) : "v"(xa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=&v"(ax[3]) : "v"(xa));
+    };
+    auto read_x_hi = [&](int xbuf, int kk, f32x4(&ax)[4]) {  // row blocks 4-7
+        const unsigned xa = xfrag16 + (unsigned)xbuf * (STG * 4u) + pcb16[kk];
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=&v"(ax[0]) : "v"(xa));
+        asm volatile("ds_read_b128 %0, %1 offset:10240" : "=&v"(ax[1]) : "v"(xa));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=&v"(ax[2]) : "v"(xa));
+        asm volatile("ds_read_b128 %0, %1 offset:14336" : "=&v"(ax[3]) : "v"(xa));
+    };
+    auto read_q16 = [&](int qbuf, int kk, f32x4(&aq)[4]) {
+        const unsigned qa = qfrag16 + (unsigned)qbuf * (STG * 4u) + pcb16[kk];
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(aq[0]) : "v"(qa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=&v"(aq[1]) : "v"(qa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=&v"(aq[2]) : "v"(qa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=&v"(aq[3]) : "v"(qa));
+    };
+    // one batch: 16 MFMAs of 16 cycles; the two LDS-DMA slots sit where the 32x32x16 batch has them (behind
+    // 64 and 192 matrix cycles)
+    auto multiply16 = [&](auto half, const f32x4(&ax)[4], const f32x4(&aq)[4], auto ld0, auto ld1) {
+        constexpr int H = decltype(half)::value;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc16[4 * H + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, ax[t]), __builtin_bit_cast(bf16x8, aq[u]), acc16[4 * H + t][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u * 4 + t == 3) ld0();
+                if (u * 4 + t == 11) ld1();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    using Half0 = std::integral_constant<int, 0>;
+    using Half1 = std::integral_constant<int, 1>;
+
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 2)
 #pragma unroll
     for (int t = 0; t < MT; ++t) fa_x[t] = fb_x[t] = f32x4{1.f * lane, 2.f, 3.f, 4.f};
@@ -380,6 +537,63 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         }
     };
 
+    // the same epilogue over 16x16 tiles: acc16[t][u][r] = row (row0 + wm * 128 + 16 t + 4 (lane >> 4) + r) against
+    // query my_q[u]
+    auto epilogue16 = [&](int row0) {
+        const bool partial = row0 + BM > nrows;
+        float best[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) best[u] = -FLT_MAX;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int rb = row0 + wm * BMW + 16 * t + 4 * lq;  // this lane's four consecutive rows
+            float xn[4];
+            if (METRIC == RAG_METRIC_L2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xn[r] = rb + r < nrows ? xnorm[rb + r] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float key[4];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc16[t][u][r];
+                    if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn[r]) - qn[u];
+                    key[r] = v;
+                    bool ok = SAMPLE || v >= thr[u];
+                    if (partial) ok = ok && (rb + r < nrows);
+                    if (SAMPLE) best[u] = ok ? fmaxf(best[u], v) : best[u];
+                    any = any || ok;
+                }
+                if (!SAMPLE && __ballot(any) != 0ULL && my_q[u] < nq) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (key[r] >= thr[u] && rb + r < nrows) {
+                            const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
+                            if (slot < (unsigned int)cap) {
+                                const long long o = (long long)my_q[u] * cap + slot;
+                                cand_key[o] = key[r];
+                                cand_id[o] = rb + r;
+                            }
+                        }
+                    }
+                }
+                acc16[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (SAMPLE) {
+            // a query's other rows of the wave tile live in lanes ^ 16, ^ 32, ^ 48
+            const int slot = 2 * (row0 / tile_rows) + wm;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float m = fmaxf(best[u], __shfl_xor(best[u], 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                if (lq == 0 && my_q[u] < nq) cand_key[(long long)my_q[u] * cap + slot] = m;
+            }
+        }
+    };
+
     // prologue: rows of stages 0 and 1 and queries of stage 0 in flight; slice 0 of stage 0 -> fa; first
     // half of the queries of stage 1
 #pragma unroll
@@ -393,51 +607,99 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     x_next();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XQ));
     __builtin_amdgcn_s_barrier();
-    read_frags(0, 0, 0, fa_x, fa_q);
-    q_ld(0);
-    q_ld(1);
+    if constexpr (M16) {
+        read_x_lo(0, 0, pa_x);
+        read_q16(0, 0, pa_q);
+        q_ld(0);
+        q_ld(1);
 
-    int xcur = 0, qcur = 0, ks = 0;
-    int row0 = s * tile_rows;
-    for (int e = 0; e < total; ++e) {
-        // loads of this iteration, in issue order: second half of the queries of stage e+1, rows of stage
-        // e+2 (both into the buffers stage e-1 used), and behind the barrier the first half of the queries
-        // of stage e+2 (into the buffer stage e used)
-        read_frags(xcur, qcur, 1, fb_x, fb_q);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));  // slice 0 has landed, slice 1 may be in flight
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(fa_x, fa_q, [&] { q_ld(2); }, [&] { q_ld(3); q_next(); });
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(xcur, qcur, 2, fa_x, fa_q);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(fb_x, fb_q, [&] { x_ld(0); }, [&] { x_ld(1); });
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(xcur, qcur, 3, fb_x, fb_q);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(fa_x, fa_q, [&] { x_ld(2); }, [&] { x_ld(3); x_next(); });
-        __builtin_amdgcn_sched_barrier(0);
-        // own loads of stage e+1 have landed (all but the four row loads of stage e+2 issued above), every
-        // fragment read of stage e has returned.  (Assembly, not the builtin: the compiler relaxes a
-        // builtin wait that it believes unnecessary.)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XQ));
-        __builtin_amdgcn_s_barrier();
-        xcur = xcur + 1 == NSX ? 0 : xcur + 1;
-        qcur ^= 1;
-        read_frags(xcur, qcur, 0, fa_x, fa_q);  // past the last stage: filler data, never multiplied
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(fb_x, fb_q, [&] { q_ld(0); }, [&] { q_ld(1); });
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks == nk - 1) {
-            // fa is in flight: let it land before compiler-scheduled code (spills included) runs
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int xcur = 0, qcur = 0, ks = 0;
+        int row0 = s * tile_rows;
+        for (int e = 0; e < total; ++e) {
+            // the LDS-DMA instructions sit in the same four batches as below; the fragment sets are
+            // pa (x: row blocks 0-3, q) and pb (x: row blocks 4-7, q of the stage's second slice)
+            read_x_hi(xcur, 0, pb_x);
+            asm volatile("s_waitcnt lgkmcnt(4)");  // slice 0: first row half and queries have landed
             __builtin_amdgcn_sched_barrier(0);
-            epilogue(row0);
+            multiply16(Half0{}, pa_x, pa_q, [&] { q_ld(2); }, [&] { q_ld(3); q_next(); });
+            __builtin_amdgcn_sched_barrier(0);
+            read_x_lo(xcur, 1, pa_x);
+            read_q16(qcur, 1, pb_q);
+            asm volatile("s_waitcnt lgkmcnt(8)");
+            __builtin_amdgcn_sched_barrier(0);
+            multiply16(Half1{}, pb_x, pa_q, [&] { x_ld(0); }, [&] { x_ld(1); });
+            __builtin_amdgcn_sched_barrier(0);
+            read_x_hi(xcur, 1, pb_x);
+            asm volatile("s_waitcnt lgkmcnt(4)");
+            __builtin_amdgcn_sched_barrier(0);
+            multiply16(Half0{}, pa_x, pb_q, [&] { x_ld(2); }, [&] { x_ld(3); x_next(); });
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XQ));
+            __builtin_amdgcn_s_barrier();
+            xcur = xcur + 1 == NSX ? 0 : xcur + 1;
+            qcur ^= 1;
+            read_x_lo(xcur, 0, pa_x);  // past the last stage: filler data, never multiplied
+            read_q16(qcur, 0, pa_q);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply16(Half1{}, pb_x, pb_q, [&] { q_ld(0); }, [&] { q_ld(1); });
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == nk - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue16(row0);
+            }
+            if (++ks == nk) {
+                ks = 0;
+                row0 += tile_stride;
+            }
         }
-        if (++ks == nk) {
-            ks = 0;
-            row0 += tile_stride;
+    } else {
+        read_frags(0, 0, 0, fa_x, fa_q);
+        q_ld(0);
+        q_ld(1);
+
+        int xcur = 0, qcur = 0, ks = 0;
+        int row0 = s * tile_rows;
+        for (int e = 0; e < total; ++e) {
+            // loads of this iteration, in issue order: second half of the queries of stage e+1, rows of stage
+            // e+2 (both into the buffers stage e-1 used), and behind the barrier the first half of the queries
+            // of stage e+2 (into the buffer stage e used)
+            read_frags(xcur, qcur, 1, fb_x, fb_q);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));  // slice 0 has landed, slice 1 may be in flight
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(fa_x, fa_q, [&] { q_ld(2); }, [&] { q_ld(3); q_next(); });
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(xcur, qcur, 2, fa_x, fa_q);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(fb_x, fb_q, [&] { x_ld(0); }, [&] { x_ld(1); });
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(xcur, qcur, 3, fb_x, fb_q);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FR));
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(fa_x, fa_q, [&] { x_ld(2); }, [&] { x_ld(3); x_next(); });
+            __builtin_amdgcn_sched_barrier(0);
+            // own loads of stage e+1 have landed (all but the four row loads of stage e+2 issued above), every
+            // fragment read of stage e has returned.  (Assembly, not the builtin: the compiler relaxes a
+            // builtin wait that it believes unnecessary.)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XQ));
+            __builtin_amdgcn_s_barrier();
+            xcur = xcur + 1 == NSX ? 0 : xcur + 1;
+            qcur ^= 1;
+            read_frags(xcur, qcur, 0, fa_x, fa_q);  // past the last stage: filler data, never multiplied
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(fb_x, fb_q, [&] { q_ld(0); }, [&] { q_ld(1); });
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == nk - 1) {
+                // fa is in flight: let it land before compiler-scheduled code (spills included) runs
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue(row0);
+            }
+            if (++ks == nk) {
+                ks = 0;
+                row0 += tile_stride;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
