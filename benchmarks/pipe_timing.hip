@@ -75,6 +75,13 @@ int main(int argc, char** argv) {
         printf("address check: %llu out of range; first: offset %lld tag %llu block %llu thread %llu\n", chk[0], (long long)chk[1],
                chk[2], chk[3] >> 32, chk[3] & 0xffffffffULL);
 #endif
+#ifdef RAG_PIPE_STAMPS
+        unsigned long long stp[8], zero8[8] = {0};
+        CK(hipMemcpyFromSymbol(stp, HIP_SYMBOL(rag::mfma::g_pipe_stamps), sizeof stp));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(rag::mfma::g_pipe_stamps), zero8, sizeof zero8));
+        if (stp[4]) printf("stamps per wave and stage: vmcnt wait %.0f cycles, barrier %.0f, stage %.0f (%llu waves)\n", (double)stp[0] / stp[4],
+                           (double)stp[1] / stp[4], (double)stp[2] / stp[4], stp[3]);
+#endif
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         const double tf = 2.0 * nq * (double)n * d / (ms * 1e-3) / 1e12;
         printf("exp %d NS %d S %d col_tiles %d %s: %.3f ms  %.0f TFLOP/s (%.1f %% of 2500)\n",

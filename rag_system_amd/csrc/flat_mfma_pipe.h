@@ -51,6 +51,18 @@
 
 #include <type_traits>
 
+#ifndef RAG_PIPE_SLOT_A0  // LDS-DMA slots of a batch of 16 MFMAs (behind MFMA number ...): waves 0-3 (A) and 4-7 (B)
+#define RAG_PIPE_SLOT_A0 3
+#define RAG_PIPE_SLOT_A1 11
+#define RAG_PIPE_SLOT_B0 3
+#define RAG_PIPE_SLOT_B1 11
+#endif
+#ifndef RAG_PIPE_TWO_LOOPS
+#define RAG_PIPE_TWO_LOOPS 0
+#endif
+#ifndef RAG_PIPE_LATE_SLEEP
+#define RAG_PIPE_LATE_SLEEP 0
+#endif
 #ifndef RAG_PIPE_LEAN
 #define RAG_PIPE_LEAN 1
 #endif
@@ -79,6 +91,13 @@ __global__ __launch_bounds__(256) void tile_queries_kernel(const f32x4* __restri
     if (q < nq) v = Qw[((long long)q * ld + ks * BKW) / 4 + chunk];
     out[i] = v;
 }
+
+#ifdef RAG_PIPE_STAMPS
+// diagnostic build (benchmarks/pipe_timing.hip -DRAG_PIPE_STAMPS): s_memtime totals per wave around the stage's
+// wait and barrier (16x16x32 path): [0] cycles in s_waitcnt vmcnt, [1] in s_barrier, [2] whole K loop, [3] waves,
+// [4] stages
+__device__ unsigned long long g_pipe_stamps[8];
+#endif
 
 #ifdef RAG_PIPE_CHECK
 // diagnostic build (benchmarks/pipe_timing.hip -DRAG_PIPE_CHECK): every LDS-DMA source address is checked
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     // byte offset of this lane's 16 bytes from px_src, per instruction; in the last, partial row tile the rows
     // past the end re-read the last row (masked in the epilogue)
     unsigned xo[XQ];
-    auto set_xo = [&]() {
+    auto set_xo = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < XQ; ++it) {
             int r = lrow + 64 * it;
@@ -227,14 +246,14 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     for (int it = 0; it < QQ; ++it) {
         qo[it] = 16u * (unsigned)((it * NWV + wid) * 64 + lane);
     }
-    auto x_ld = [&](int it) {
+    auto x_ld = [&](int it) __attribute__((always_inline)) {
         float* dst = Xs + px_buf * STG + (it * NWV + wid) * 256;
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
         if (px_tiles_left < my_tiles) return;  // ablation: no loads after the first row tile
 #endif
         RAG_GLDS(px_src + (unsigned long long)xo[it], dst, Xb, (long long)n * ld * 4, 1);
     };
-    auto x_next = [&]() {
+    auto x_next = [&]() __attribute__((always_inline)) {
         px_buf = px_buf + 1 == NSX ? 0 : px_buf + 1;
         if (px_tiles_left > 0) {
             if (++px_ks == nk) {
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
             }
         }
     };
-    auto q_ld = [&](int it) {
+    auto q_ld = [&](int it) __attribute__((always_inline)) {
         float* dst = Qs + pq_buf * STG + (it * NWV + wid) * 256;
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
         return;
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         asm volatile("" : "+v"(o));
         RAG_GLDS(pq_src + (unsigned long long)o, dst, Qtb, (long long)nk * STG * 4, 3);
     };
-    auto q_next = [&]() {
+    auto q_next = [&]() __attribute__((always_inline)) {
         pq_buf ^= 1;
         if (++pq_ks == nk) {
             pq_ks = 0;
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     int px_ks = 0, px_buf = 0;
     int pq_left = total;
     int pq_ks = 0, pq_buf = 0;
-    auto x_ld = [&](int it) {
+    auto x_ld = [&](int it) __attribute__((always_inline)) {
         float* dst = Xs + px_buf * STG + (it * NWV + wid) * 256;
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
         if (px_tiles_left < my_tiles) return;  // ablation: no loads after the first row tile
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
             glds16(zero16, dst);
         }
     };
-    auto x_next = [&]() {
+    auto x_next = [&]() __attribute__((always_inline)) {
         px_buf = px_buf + 1 == NSX ? 0 : px_buf + 1;
         if (px_tiles_left > 0 && ++px_ks == nk) {
             px_ks = 0;
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
             --px_tiles_left;
         }
     };
-    auto q_ld = [&](int it) {
+    auto q_ld = [&](int it) __attribute__((always_inline)) {
         float* dst = Qs + pq_buf * STG + (it * NWV + wid) * 256;
 #if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 1)
         if (pq_left + nk < total) return;
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         if (pq_left > 0) RAG_GLDS(Qt + (long long)pq_ks * STG + ((it * NWV + wid) * 64 + lane) * 4, dst, Qt, (long long)nk * STG * 4, 3);
         else glds16(zero16, dst);
     };
-    auto q_next = [&]() {
+    auto q_next = [&]() __attribute__((always_inline)) {
         pq_buf ^= 1;
         if (pq_left > 0) {
             pq_ks = pq_ks + 1 == nk ? 0 : pq_ks + 1;
@@ -425,22 +444,31 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     for (int kk = 0; kk < 2; ++kk) pcb16[kk] = 16u * (unsigned)((kk * 4 + lq) ^ swz<BK>(l16));
     f32x4 pa_x[4], pb_x[4], pa_q[4], pb_q[4];
     static_assert(16 * LDS_LD * 4 == 2048, "fragment offsets below");
-    auto read_x_lo = [&](int xbuf, int kk, f32x4(&ax)[4]) {  // row blocks 0-3 of slice kk
+    auto read_x_lo = [&](int xbuf, int kk, f32x4(&ax)[4]) __attribute__((always_inline)) {  // row blocks 0-3 of slice kk
         const unsigned xa = xfrag16 + (unsigned)xbuf * (STG * 4u) + pcb16[kk];
+#if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 2)
+        return;
+#endif
         asm volatile("ds_read_b128 %0, %1" : "=&v"(ax[0]) : "v"(xa));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=&v"(ax[1]) : "v"(xa));
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=&v"(ax[2]) : "v"(xa));
         asm volatile("ds_read_b128 %0, %1 offset:6144" : "=&v"(ax[3]) : "v"(xa));
     };
-    auto read_x_hi = [&](int xbuf, int kk, f32x4(&ax)[4]) {  // row blocks 4-7
+    auto read_x_hi = [&](int xbuf, int kk, f32x4(&ax)[4]) __attribute__((always_inline)) {  // row blocks 4-7
         const unsigned xa = xfrag16 + (unsigned)xbuf * (STG * 4u) + pcb16[kk];
+#if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 2)
+        return;
+#endif
         asm volatile("ds_read_b128 %0, %1 offset:8192" : "=&v"(ax[0]) : "v"(xa));
         asm volatile("ds_read_b128 %0, %1 offset:10240" : "=&v"(ax[1]) : "v"(xa));
         asm volatile("ds_read_b128 %0, %1 offset:12288" : "=&v"(ax[2]) : "v"(xa));
         asm volatile("ds_read_b128 %0, %1 offset:14336" : "=&v"(ax[3]) : "v"(xa));
     };
-    auto read_q16 = [&](int qbuf, int kk, f32x4(&aq)[4]) {
+    auto read_q16 = [&](int qbuf, int kk, f32x4(&aq)[4]) __attribute__((always_inline)) {
         const unsigned qa = qfrag16 + (unsigned)qbuf * (STG * 4u) + pcb16[kk];
+#if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 2)
+        return;
+#endif
         asm volatile("ds_read_b128 %0, %1" : "=&v"(aq[0]) : "v"(qa));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=&v"(aq[1]) : "v"(qa));
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=&v"(aq[2]) : "v"(qa));
@@ -448,8 +476,16 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     };
     // one batch: 16 MFMAs of 16 cycles; the two LDS-DMA slots sit where the 32x32x16 batch has them (behind
     // 64 and 192 matrix cycles)
-    auto multiply16 = [&](auto half, const f32x4(&ax)[4], const f32x4(&aq)[4], auto ld0, auto ld1) {
+    auto multiply16 = [&](auto half, auto late, const f32x4(&ax)[4], const f32x4(&aq)[4], auto ld0, auto ld1) __attribute__((always_inline)) {
         constexpr int H = decltype(half)::value;
+        constexpr int S0 = decltype(late)::value ? RAG_PIPE_SLOT_B0 : RAG_PIPE_SLOT_A0;
+        constexpr int S1 = decltype(late)::value ? RAG_PIPE_SLOT_B1 : RAG_PIPE_SLOT_A1;
+#if defined(RAG_PIPE_EXP) && (RAG_PIPE_EXP & 4)
+        acc16[4 * H][0][0] += ax[0][0] * aq[0][0];  // ablation: no MFMA
+        ld0();
+        ld1();
+        return;
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -457,8 +493,8 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
                 acc16[4 * H + t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, ax[t]), __builtin_bit_cast(bf16x8, aq[u]), acc16[4 * H + t][u], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (u * 4 + t == 3) ld0();
-                if (u * 4 + t == 11) ld1();
+                if (u * 4 + t == S0) ld0();
+                if (u * 4 + t == S1) ld1();
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
@@ -470,6 +506,11 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     for (int t = 0; t < MT; ++t) fa_x[t] = fb_x[t] = f32x4{1.f * lane, 2.f, 3.f, 4.f};
 #pragma unroll
     for (int u = 0; u < NT; ++u) fa_q[u] = fb_q[u] = f32x4{1.f, 2.f * lane, 3.f, 4.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        pa_x[t] = pb_x[t] = f32x4{1.f * lane, 2.f, 3.f, 4.f};
+        pa_q[t] = pb_q[t] = f32x4{1.f, 2.f * lane, 3.f, 4.f};
+    }
 #endif
 
     // The filter epilogue of a finished row tile (rows row0 .. row0 + BM): every accumulator against its
@@ -539,50 +580,34 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
 
     // the same epilogue over 16x16 tiles: acc16[t][u][r] = row (row0 + wm * 128 + 16 t + 4 (lane >> 4) + r) against
     // query my_q[u]
-    auto epilogue16 = [&](int row0) {
-        const bool partial = row0 + BM > nrows;
-        float best[4];
+    auto epilogue16 = [&](int row0) __attribute__((always_inline)) {
+        const int rb0 = row0 + wm * BMW + 4 * lq;  // this lane's four consecutive rows of row block t: rb0 + 16 t ...
+        auto key_of = [&](float v, float xn, int u) __attribute__((always_inline)) {
+            return METRIC == RAG_METRIC_L2 ? (2.f * v - xn) - qn[u] : v;
+        };
+        if (SAMPLE) {
+            const bool partial = row0 + BM > nrows;
+            float best[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) best[u] = -FLT_MAX;
+            for (int u = 0; u < 4; ++u) best[u] = -FLT_MAX;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int rb = row0 + wm * BMW + 16 * t + 4 * lq;  // this lane's four consecutive rows
-            float xn[4];
-            if (METRIC == RAG_METRIC_L2) {
+            for (int t = 0; t < 8; ++t) {
+                const int rb = rb0 + 16 * t;
+                float xn[4] = {0.f, 0.f, 0.f, 0.f};
+                if (METRIC == RAG_METRIC_L2) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xn[r] = rb + r < nrows ? xnorm[rb + r] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float key[4];
-                bool any = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc16[t][u][r];
-                    if (METRIC == RAG_METRIC_L2) v = (2.f * v - xn[r]) - qn[u];
-                    key[r] = v;
-                    bool ok = SAMPLE || v >= thr[u];
-                    if (partial) ok = ok && (rb + r < nrows);
-                    if (SAMPLE) best[u] = ok ? fmaxf(best[u], v) : best[u];
-                    any = any || ok;
+                    for (int r = 0; r < 4; ++r) xn[r] = rb + r < nrows ? xnorm[rb + r] : 0.f;
                 }
-                if (!SAMPLE && __ballot(any) != 0ULL && my_q[u] < nq) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (key[r] >= thr[u] && rb + r < nrows) {
-                            const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
-                            if (slot < (unsigned int)cap) {
-                                const long long o = (long long)my_q[u] * cap + slot;
-                                cand_key[o] = key[r];
-                                cand_id[o] = rb + r;
-                            }
-                        }
+                        const float v = key_of(acc16[t][u][r], xn[r], u);
+                        best[u] = (!partial || rb + r < nrows) ? fmaxf(best[u], v) : best[u];
                     }
+                    acc16[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                acc16[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        }
-        if (SAMPLE) {
             // a query's other rows of the wave tile live in lanes ^ 16, ^ 32, ^ 48
             const int slot = 2 * (row0 / tile_rows) + wm;
 #pragma unroll
@@ -591,7 +616,82 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
                 if (lq == 0 && my_q[u] < nq) cand_key[(long long)my_q[u] * cap + slot] = m;
             }
+            return;
         }
+        if (METRIC == RAG_METRIC_L2) {
+            // filter pass, L2: every key needs its row's norm; row block by row block
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int rb = rb0 + 16 * t;
+                float xn[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xn[r] = rb + r < nrows ? xnorm[rb + r] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float key[4];
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        key[r] = key_of(acc16[t][u][r], xn[r], u);
+                        any = any || (key[r] >= thr[u] && rb + r < nrows);
+                    }
+                    if (__ballot(any) != 0ULL && my_q[u] < nq) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (key[r] >= thr[u] && rb + r < nrows) {
+                                const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
+                                if (slot < (unsigned int)cap) {
+                                    const long long o = (long long)my_q[u] * cap + slot;
+                                    cand_key[o] = key[r];
+                                    cand_id[o] = rb + r;
+                                }
+                            }
+                        }
+                    }
+                    acc16[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            return;
+        }
+        // Filter pass, inner product.  First the best score per query over the lane's 32 rows (a maximum per
+        // element instead of a comparison, a select and an OR; rows past the end of a partial tile hold the last
+        // row again and are sorted out below); only a (wave, query block) in which some lane has a passing score
+        // looks at its elements.
+        float m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = -FLT_MAX;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m[u] = fmaxf(m[u], acc16[t][u][r]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (__ballot(m[u] >= thr[u]) != 0ULL && my_q[u] < nq) {
+                // rare: append every passing row of this lane's query to its buffer
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int rb = rb0 + 16 * t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float key = acc16[t][u][r];
+                        if (key >= thr[u] && rb + r < nrows) {
+                            const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
+                            if (slot < (unsigned int)cap) {
+                                const long long o = (long long)my_q[u] * cap + slot;
+                                cand_key[o] = key;
+                                cand_id[o] = rb + r;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc16[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     // prologue: rows of stages 0 and 1 and queries of stage 0 in flight; slice 0 of stage 0 -> fa; first
@@ -613,46 +713,86 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
         q_ld(0);
         q_ld(1);
 
-        int xcur = 0, qcur = 0, ks = 0;
-        int row0 = s * tile_rows;
-        for (int e = 0; e < total; ++e) {
-            // the LDS-DMA instructions sit in the same four batches as below; the fragment sets are
-            // pa (x: row blocks 0-3, q) and pb (x: row blocks 4-7, q of the stage's second slice)
-            read_x_hi(xcur, 0, pb_x);
-            asm volatile("s_waitcnt lgkmcnt(4)");  // slice 0: first row half and queries have landed
-            __builtin_amdgcn_sched_barrier(0);
-            multiply16(Half0{}, pa_x, pa_q, [&] { q_ld(2); }, [&] { q_ld(3); q_next(); });
-            __builtin_amdgcn_sched_barrier(0);
-            read_x_lo(xcur, 1, pa_x);
-            read_q16(qcur, 1, pb_q);
-            asm volatile("s_waitcnt lgkmcnt(8)");
-            __builtin_amdgcn_sched_barrier(0);
-            multiply16(Half1{}, pb_x, pa_q, [&] { x_ld(0); }, [&] { x_ld(1); });
-            __builtin_amdgcn_sched_barrier(0);
-            read_x_hi(xcur, 1, pb_x);
-            asm volatile("s_waitcnt lgkmcnt(4)");
-            __builtin_amdgcn_sched_barrier(0);
-            multiply16(Half0{}, pa_x, pb_q, [&] { x_ld(2); }, [&] { x_ld(3); x_next(); });
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XQ));
-            __builtin_amdgcn_s_barrier();
-            xcur = xcur + 1 == NSX ? 0 : xcur + 1;
-            qcur ^= 1;
-            read_x_lo(xcur, 0, pa_x);  // past the last stage: filler data, never multiplied
-            read_q16(qcur, 0, pa_q);
-            __builtin_amdgcn_sched_barrier(0);
-            multiply16(Half1{}, pb_x, pb_q, [&] { q_ld(0); }, [&] { q_ld(1); });
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks == nk - 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // The two waves that share a SIMD (wave w and w + 4, i.e. wm = 0 and 1) run the same program in step, so
+        // with the same slots both would sit in LDS-DMA issue at the same time and leave the matrix pipe idle;
+        // the second one issues its loads half a batch later.
+        auto k_loop = [&](auto late) __attribute__((always_inline)) {
+            int xcur = 0, qcur = 0, ks = 0;
+            int row0 = s * tile_rows;
+#ifdef RAG_PIPE_STAMPS
+            unsigned long long st_vm = 0, st_bar = 0;
+            const unsigned long long st_t0 = __builtin_readcyclecounter();
+#endif
+            for (int e = 0; e < total; ++e) {
+                // the LDS-DMA instructions sit in the same four batches as below; the fragment sets are
+                // pa (x: row blocks 0-3, q) and pb (x: row blocks 4-7, q of the stage's second slice)
+                read_x_hi(xcur, 0, pb_x);
+                asm volatile("s_waitcnt lgkmcnt(4)");  // slice 0: first row half and queries have landed
                 __builtin_amdgcn_sched_barrier(0);
-                epilogue16(row0);
+                multiply16(Half0{}, late, pa_x, pa_q, [&] { q_ld(2); }, [&] { q_ld(3); q_next(); });
+                __builtin_amdgcn_sched_barrier(0);
+                read_x_lo(xcur, 1, pa_x);
+                read_q16(qcur, 1, pb_q);
+                asm volatile("s_waitcnt lgkmcnt(8)");
+                __builtin_amdgcn_sched_barrier(0);
+                multiply16(Half1{}, late, pb_x, pa_q, [&] { x_ld(0); }, [&] { x_ld(1); });
+                __builtin_amdgcn_sched_barrier(0);
+                read_x_hi(xcur, 1, pb_x);
+                asm volatile("s_waitcnt lgkmcnt(4)");
+                __builtin_amdgcn_sched_barrier(0);
+                multiply16(Half0{}, late, pa_x, pb_q, [&] { x_ld(2); }, [&] { x_ld(3); x_next(); });
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef RAG_PIPE_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                const unsigned long long ta_ = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XQ));
+                const unsigned long long tb_ = __builtin_readcyclecounter();
+                __builtin_amdgcn_s_barrier();
+                const unsigned long long tc_ = __builtin_readcyclecounter();
+                st_vm += tb_ - ta_;
+                st_bar += tc_ - tb_;
+                __builtin_amdgcn_sched_barrier(0);
+#else
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XQ));
+                __builtin_amdgcn_s_barrier();
+#endif
+#if RAG_PIPE_LATE_SLEEP
+                if (wm != 0) __builtin_amdgcn_s_sleep(RAG_PIPE_LATE_SLEEP);  // de-phase the two waves of a SIMD
+#endif
+                xcur = xcur + 1 == NSX ? 0 : xcur + 1;
+                qcur ^= 1;
+                read_x_lo(xcur, 0, pa_x);  // past the last stage: filler data, never multiplied
+                read_q16(qcur, 0, pa_q);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply16(Half1{}, late, pb_x, pb_q, [&] { q_ld(0); }, [&] { q_ld(1); });
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == nk - 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    epilogue16(row0);
+                }
+                if (++ks == nk) {
+                    ks = 0;
+                    row0 += tile_stride;
+                }
             }
-            if (++ks == nk) {
-                ks = 0;
-                row0 += tile_stride;
+#ifdef RAG_PIPE_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                atomicAdd(&g_pipe_stamps[0], st_vm);
+                atomicAdd(&g_pipe_stamps[1], st_bar);
+                atomicAdd(&g_pipe_stamps[2], __builtin_readcyclecounter() - st_t0);
+                atomicAdd(&g_pipe_stamps[3], 1ULL);
+                atomicAdd(&g_pipe_stamps[4], (unsigned long long)total);
             }
-        }
+#endif
+        };
+#if RAG_PIPE_TWO_LOOPS
+        if (wm == 0) k_loop(std::integral_constant<bool, false>{});
+        else k_loop(std::integral_constant<bool, true>{});
+#else
+        k_loop(std::integral_constant<bool, false>{});
+#endif
     } else {
         read_frags(0, 0, 0, fa_x, fa_q);
         q_ld(0);
