@@ -164,7 +164,8 @@ def kernel_name(nq, k, n_local, bf, d=0):
     if nq <= 192 and n_local >= (1 << 19) and (nq <= 64 or not bf):
         return "flat_wide_kernel (sample + filter passes%s)" % (
             "" if nq <= 64 else ", %d query chunks" % ((nq + 63) // 64))
-    if bf and nq > 64 and d % 64 == 0 and k >= (16 if nq <= 128 else 33):
+    # rows of whole 128-byte K stages: bf16 from 65 queries (k >= 16 up to 128 queries), fp32 from 129; every k above 128
+    if (d * (2 if bf else 4)) % 128 == 0 and ((bf and 64 < nq <= 128 and k >= 16) or nq > 128):
         return "flat_pipe_kernel (filter flow: sample pass + filter pass)"
     return "flat_mfma_kernel"
 

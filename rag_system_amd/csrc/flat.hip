@@ -1339,9 +1339,14 @@ int search_device(rag_flat* h, int64_t nq, const float* q_dev, int k, float* D_d
         // tile kernel as their redo path)
         const bool wide = plan_ok && nq >= wide_min_nq && opt.mfma_filter_k <= 1 && n >= opt.mfma_filter_min_rows &&
                           wide_plan(n, nq, dch, bf, j, cap, FILTER_STEP, &wp);
+        // more than 128 queries over rows of whole 128-byte stages: the pipelined tile kernel (flat_mfma_pipe.h)
+        // only has sample and filter passes and beats the list-mode tile kernel at every k (10M x 384 fp32,
+        // nq 1024, k 10: 57.2 ms for the whole flow against 62.1; benchmarks/ab/run_r03_f32_pipe.sh)
+        const bool pipe_any_k = !stream_ok && nq > 128 && (ld * h->esz / 4) % 32 == 0 && opt.mfma_shape == 0;
         const int64_t filter_k = opt.mfma_filter_k > 0 ? opt.mfma_filter_k
                                  : wide                ? 1
                                  : stream_ok           ? (nq > 8 ? 24 : (nq >= 4 ? 65 : 129))
+                                 : pipe_any_k          ? 1
                                                        : (nq <= 128 ? 16 : 33);
         const bool filter = plan_ok && k >= filter_k && n >= opt.mfma_filter_min_rows &&
                             mfma_plan(std::max<long long>(1, n / FILTER_STEP), nq, j, bf, &ps) &&

@@ -87,7 +87,9 @@ bool mfma_plan_filter(long long n, long long nq, bool bf16, int cap, MfmaPlan* p
     // flat_mfma_pipe.h (config C3: 17.x ms per batch against 19.1 for shape 4; 65-128 queries, where its
     // 256-query tile is half empty: 10M x 768, k 100: 3.87-3.99 ms against 4.13-4.31 for the 128-query tile
     // kernel, 10M x 384: 2.18-2.23 against 2.52-2.61; benchmarks/ab/run_pipe_mid.sh)
-    if (nq > 64 && bf16 && ld_words > 0 && ld_words % 32 == 0) shape = 9;
+    // fp32 rows, more than 128 queries (up to 192 go to the register-fed kernel of flat_wide.hip on large shards):
+    // 10M x 384, nq 1024: filter pass 56.2 ms against 62.1 ms for the list-mode pass of shape 4 (r03)
+    if (nq > (bf16 ? 64 : 128) && ld_words > 0 && ld_words % 32 == 0) shape = 9;
     const long long force = options().mfma_shape;
     if ((force >= 1 && force <= 4) || (force >= 7 && force <= 10)) shape = (int)force - 1;
     int NS = 3;
