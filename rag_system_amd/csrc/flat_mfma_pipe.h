@@ -516,6 +516,50 @@ __global__ __launch_bounds__(512, 2) void flat_pipe_kernel(
     // The filter epilogue of a finished row tile (rows row0 .. row0 + BM): every accumulator against its
     // query's threshold, passing rows appended through the query's counter, accumulators cleared.
     auto epilogue = [&](int row0) {
+        if (!SAMPLE && METRIC == RAG_METRIC_IP) {
+            // Filter pass, inner product (as in epilogue16): first the best score per query over the lane's 64 rows
+            // -- one v_max3 per two accumulators instead of a comparison, a select and an OR per accumulator; rows
+            // past the end of a partial tile hold the last row again and are sorted out below -- and only a
+            // (wave, query block) in which some lane has a passing score looks at its elements.
+            float m[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) m[u] = -FLT_MAX;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[u] = fmaxf(m[u], acc[t][u][r]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                if (__ballot(m[u] >= thr[u]) != 0ULL && my_q[u] < nq) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const int rowbase = row0 + wm * BMW + 32 * t;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ro = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const float key = acc[t][u][r];
+                            if (key >= thr[u] && rowbase + ro < nrows) {
+                                const unsigned int slot = atomicAdd(&counts[my_q[u]], 1u);
+                                if (slot < (unsigned int)cap) {
+                                    const long long o = (long long)my_q[u] * cap + slot;
+                                    cand_key[o] = key;
+                                    cand_id[o] = rowbase + ro;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+            return;
+        }
         const bool partial = row0 + BM > nrows;
         float best[NT];  // SAMPLE: this lane's best score per query over the wave's 128 rows
 #pragma unroll
