@@ -533,3 +533,32 @@ def test_mfma_filter_mode_default_thresholds(engine):
     finally:
         _with_options(lib, {"wide_max_nq": 0})
     assert np.array_equal(I2, I3) and np.array_equal(D2, D3)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_large_batches_take_the_pipelined_filter_flow_at_every_k(engine, metric):
+    """More than 128 queries over rows of whole 128-byte stages on a shard of 512k+ rows: the default route is
+    the pipelined tile kernel's filter flow whatever k is (r03; fp32 rows here, 600k x 64, k = 5 and 1);
+    ids as the oracle's, and as the list-mode tile kernel's."""
+    from rag_system_amd import _lib
+    lib = _lib.engine()
+    rng = np.random.default_rng(2024 + metric)
+    X = _rand_unit(rng, 600_000, 64)
+    X[599_999] = X[7]
+    X[300_000] = X[7]
+    Q = _rand_unit(rng, 200, 64)
+    Q[0] = X[7]
+    idx = _index(64, metric)
+    idx.add(X)
+    for k in (5, 1):
+        D, I = idx.search(Q, k)
+        assert "tile filter" in idx._b.last_kernel(), idx._b.last_kernel()
+        _, Ir, D64 = od.flat_search(X, Q, k, metric)
+        od.check_topk(D, I, D64, Ir, RTOL, ATOL if metric == 0 else 4e-6, _scorer(X, Q, metric))
+        try:
+            _with_options(lib, {"mfma_filter_k": 1000})
+            D2, I2 = idx.search(Q, k)
+            assert "tile list" in idx._b.last_kernel(), idx._b.last_kernel()
+        finally:
+            _with_options(lib, {"mfma_filter_k": 0})
+        assert np.array_equal(I, I2) and np.array_equal(D, D2)   # same K order per accumulator: bit-identical
