@@ -22,10 +22,10 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
-for src, dst in (("default_stats", "bench_default"), ("nq1_stats", "bench_nq1"), ("c3_stats", "bench_c3_bf16_nq1024_k100"), ("hyb_stats", "bench_hybrid_1m")):
+for src, dst in (("default_stats", "bench_default"), ("nq1_stats", "bench_nq1"), ("c3_stats", "bench_c3_bf16_nq1024_k100"), ("hyb_stats", "bench_hybrid_1m"), ("b1024_stats", "bench_nq1024")):
     shutil.copy(newest(P + src + "/*/*_kernel_stats.csv"), "profiles/%s_%s_kernel_stats.csv" % (tag, dst))
 for src, dst in (("default_under_rocprof", "bench_default_under_rocprof"), ("nq1_under_rocprof", "bench_nq1_under_rocprof"), ("c3_under_rocprof", "bench_c3_under_rocprof"),
-                 ("hyb_under_rocprof", "bench_hybrid_1m_under_rocprof")):
+                 ("hyb_under_rocprof", "bench_hybrid_1m_under_rocprof"), ("b1024_under_rocprof", "bench_nq1024_under_rocprof")):
     shutil.copy(P + src + ".json", "profiles/%s_%s.json" % (tag, dst))
 
 if os.path.exists(P + "default_plain.json") and os.path.getsize(P + "default_plain.json"):
@@ -56,8 +56,24 @@ d["derived"] = {"cycles_per_xcd": cyc, "mfma_busy_frac": d["SQ_VALU_MFMA_BUSY_CY
                 "hbm_read_bytes": d["FETCH_SIZE"] * 1024 * 2,
                 "note": "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_32x32x16_bf16) summed over the 1024 SIMDs; "
                         "clock = cycles_per_xcd / the kernel's duration in the kernel stats of the same workload"}
-json.dump({"bf16_768_nq1024_k100_pipelined_kernel_filter_pass": d}, open("profiles/%s_mfma_pmc.json" % tag, "w"), indent=1)
+out = {"bf16_768_nq1024_k100_pipelined_kernel_filter_pass": d}
 print(json.dumps(d["derived"], indent=1))
+
+# the fp32 half of the headline (10M x 384, nq 1024, k 10) through the same kernel (32x32x2 fp32 tiles)
+if os.path.exists(P + "b1024_sq.json"):
+    f = {"kernels": {}}
+    for n in ("b1024_sq", "b1024_grbm"):
+        kname, cs = only(ld(n))
+        f["kernels"][n] = kname
+        f.update({k: v["mean"] for k, v in cs.items()})
+    cyc = f["GRBM_GUI_ACTIVE"] / 8
+    f["derived"] = {"cycles_per_xcd": cyc, "mfma_busy_frac": f["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
+                    "wait_any_frac": f["SQ_WAIT_ANY"] / f["SQ_WAVE_CYCLES"],
+                    "wait_inst_any_frac": f["SQ_WAIT_INST_ANY"] / f["SQ_WAVE_CYCLES"],
+                    "note": "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (64 per v_mfma_f32_32x32x2_f32) summed over the 1024 SIMDs"}
+    out["f32_384_nq1024_k10_pipelined_kernel_filter_pass"] = f
+    print(json.dumps(f["derived"], indent=1))
+json.dump(out, open("profiles/%s_mfma_pmc.json" % tag, "w"), indent=1)
 
 # agreement of the two clocks on the batch-1 kernel (same run)
 import csv
