@@ -263,17 +263,6 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
     const int b = lane >> 2, j = lane & 3;   // k slice (16-byte chunk within a 256-byte segment), query in group
     const int dchp = ((dch + 16 * NB - 1) / (16 * NB)) * (16 * NB);  // whole segments, a multiple of NB of them
 
-    // queries: chunk c of query 4g+jj at q_lds[(g*dchp + c)*4 + jj] -> one lane-linear b128 read per
-    // (segment, group); missing queries and the chunks past the row end are zeros
-    for (int i = tid; i < G * dchp * 4; i += ST_THREADS) {
-        const int jj = i & 3, c = (i >> 2) % dchp, g = (i >> 2) / dchp;
-        const int q = 4 * g + jj;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (q < nq && c < dch) v = Q[(long long)q * dch + c];
-        q_lds[i] = v;
-    }
-    __syncthreads();
-
     constexpr int NL = FILT ? 1 : 4 * G;
     using TK = WaveTopK<float, int, KS>;
     TK tk[NL];
@@ -353,6 +342,17 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
         for (int rg = 0; rg < RG; ++rg) buf[p][rg] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int p = 0; p + 1 < NB; ++p) issue(buf[p]);
+    // queries (staged BEHIND the first row loads, so that the two round trips to memory overlap instead of
+    // following each other: ~1.5 us per launch): chunk c of query 4g+jj at q_lds[(g*dchp + c)*4 + jj] -> one
+    // lane-linear b128 read per (segment, group); missing queries and the chunks past the row end are zeros
+    for (int i = tid; i < G * dchp * 4; i += ST_THREADS) {
+        const int jj = i & 3, c = (i >> 2) % dchp, g = (i >> 2) / dchp;
+        const int q = 4 * g + jj;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q < nq && c < dch) v = Q[(long long)q * dch + c];
+        q_lds[i] = v;
+    }
+    __syncthreads();
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto bf_half = [](const u32x4& v, int e) {
