@@ -248,6 +248,19 @@ __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const fl
 #ifndef RAG_STREAM_MINB
 #define RAG_STREAM_MINB (G * RG >= 8 ? 3 : 4)  // blocks per CU the register budget must admit
 #endif
+#ifdef RAG_STREAM_STAMPS
+// diagnostic build (benchmarks/build_variant.sh stamps flat_stream.hip -DRAG_STREAM_STAMPS; benchmarks/stream_stamps.py):
+// lane 0 of wave 0 of every block records the constant 100 MHz clock at [0] kernel entry, [1] queries staged (first
+// row loads in flight), [2] end of the row loop, [3] block list stored, [4] ticket drawn, [5] fused merge done (last
+// block only).  Never in the product build.
+__device__ unsigned long long g_stream_stamps[1024 * 8];
+#define RAG_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_stream_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define RAG_STAMP(i)
+#endif
 template <int G, int RG, int KS, int METRIC, bool BF, bool FILT, int NB>
 __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kernel(
     const u32x4* __restrict__ X, long long n, int dch, const u32x4* __restrict__ Q, int nq, int k,
@@ -256,6 +269,7 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
     const float* __restrict__ thr_q, unsigned int* __restrict__ counts, int cap, unsigned int* __restrict__ ticket,
     float* __restrict__ D, long long* __restrict__ I, long long id_base) {
     if (run_flag != nullptr && *run_flag == 0) return;  // uniform, before any barrier
+    RAG_STAMP(0);
     extern __shared__ __align__(16) unsigned char smem_raw[];
     u32x4* q_lds = reinterpret_cast<u32x4*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -353,6 +367,7 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
         q_lds[i] = v;
     }
     __syncthreads();
+    RAG_STAMP(1);
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto bf_half = [](const u32x4& v, int e) {
@@ -471,6 +486,7 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
         }
     }
 
+    RAG_STAMP(2);
     if (FILT) return;
     // ---- merge the block's four wave lists through LDS (over the query area): every wave posts its
     // lists, wave w merges the queries q = w (mod 4) -- the tail of the kernel is a chain of sorted
@@ -522,6 +538,7 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
             }
         }
     }
+    RAG_STAMP(3);
     if constexpr (G != 1 || KS != 1) return;  // the fused merge exists for 1-2 queries with k <= 16 only
     if (D == nullptr) return;  // uniform: the caller merges the lists with flat_merge_kernel
     // ---- fused merge: every storing wave drains its (write-through) stores, the block's barrier, then ONE
@@ -563,9 +580,11 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
     }
 #endif
     __syncthreads();
+    RAG_STAMP(4);
     if (*last == 0) return;
     __syncthreads();  // *last is read by everyone before the merge reuses the LDS
     stream_fused_merge<METRIC>(smem_raw, cand_key, cand_id, (int)gridDim.x, nq, k, D, I, id_base);
+    RAG_STAMP(5);
 }
 
 struct Args {
@@ -711,3 +730,12 @@ int stream_launch(const StreamPlan& p, const void* X, long long n, int dch, cons
 }
 
 }  // namespace rag
+
+#ifdef RAG_STREAM_STAMPS
+extern "C" int rag_debug_stream_stamps(unsigned long long* out, int n_words) {
+    if (n_words > 1024 * 8) n_words = 1024 * 8;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rag::g_stream_stamps), (size_t)n_words * 8) != hipSuccess) return -1;
+    return 0;
+}
+#endif
