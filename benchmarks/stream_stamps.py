@@ -53,13 +53,12 @@ def main():
         rel = (s[:, :5] - t0) / 100.0          # microseconds
         last = int(np.argmax(s[:, 4]))
         agg.append([rel[:, i].min() for i in range(5)] + [np.median(rel[:, i]) for i in range(5)]
-                   + [rel[:, i].max() for i in range(5)] + [(s[last, 5] - t0) / 100.0, (s[last, 6] - t0) / 100.0,
-                                                            (s[last, 7] - t0) / 100.0])
+                   + [rel[:, i].max() for i in range(5)] + [(s[last, 5] - t0) / 100.0])
     a = np.median(np.array(agg), axis=0)
     print("%d blocks; microseconds after the first block's entry (median over %d launches)" % (nb, len(agg)))
     for i, n in enumerate(names):
         print("  %-16s first %8.2f   median %8.2f   last %8.2f" % (n, a[i], a[5 + i], a[10 + i]))
-    print("  last block: lists in registers %8.2f   threshold known %8.2f   fused merge done %8.2f" % (a[16], a[17], a[15]))
+    print("  fused merge done (last block)  %8.2f" % a[15])
 
 
 if __name__ == "__main__":
