@@ -114,7 +114,11 @@ __device__ __forceinline__ unsigned long long fuse_pack(float key, int id) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)id);
 }
 
-template <int METRIC>
+// KMAX: list entries held per list (k <= KMAX <= FUSE_MAX_K).  The merge runs once per launch, in one block, on cold
+// code; every entry slot is unrolled code (loads, compares, candidate stores), and ten slots instead of sixteen make the
+// kernel 1.0-1.2 us shorter at k = 10 (benchmarks/ab/run_r03_fuse_code_size.sh: 1M rows 0.2351 -> 0.2342 ms, 20k rows
+// 28.4 -> 27.2 us), so the reference's default top_k gets its own instance.
+template <int METRIC, int KMAX>
 __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const float* cand_key, const int* cand_id,
                                                    int nlists, int nq, int k, float* __restrict__ D,
                                                    long long* __restrict__ I, long long id_base) {
@@ -142,13 +146,13 @@ __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const fl
         const float* ck = cand_key + (long long)q * nlists * k;
         const int* ci = cand_id + (long long)q * nlists * k;
         // this thread's lists, whole, in one round trip; entries past k and lists past nlists are padding
-        float key[FUSE_LPT][FUSE_MAX_K];
-        int id[FUSE_LPT][FUSE_MAX_K];
+        float key[FUSE_LPT][KMAX];
+        int id[FUSE_LPT][KMAX];
 #pragma unroll
         for (int u = 0; u < FUSE_LPT; ++u) {
             const int l = tid + u * ST_THREADS;
 #pragma unroll
-            for (int e = 0; e < FUSE_MAX_K; ++e) {
+            for (int e = 0; e < KMAX; ++e) {
                 key[u][e] = -FLT_MAX;
                 id[u][e] = IdPad<int>::v();
                 if (l < nlists && e < k) {
@@ -190,14 +194,14 @@ __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const fl
             int c = 0;
             bool more = true;
 #pragma unroll
-            for (int e = 0; e < FUSE_MAX_K; ++e) {
+            for (int e = 0; e < KMAX; ++e) {
                 more = more && key[u][e] >= T && id[u][e] != IdPad<int>::v();
                 c += more ? 1 : 0;
             }
             if (c > 0) {
                 const int slot = atomicAdd(n_cand, c);
 #pragma unroll
-                for (int e = 0; e < FUSE_MAX_K; ++e)
+                for (int e = 0; e < KMAX; ++e)
                     if (e < c && slot + e < FUSE_CAP) sv[slot + e] = fuse_pack(key[u][e], id[u][e]);
             }
         }
@@ -227,7 +231,7 @@ __device__ __forceinline__ void stream_fused_merge(unsigned char* smem, const fl
             for (int u = 0; u < FUSE_LPT; ++u) {
                 cur[u] = 0ULL;
 #pragma unroll
-                for (int e = 0; e < FUSE_MAX_K; ++e)
+                for (int e = 0; e < KMAX; ++e)
                     if (e == pos[u] && id[u][e] != IdPad<int>::v()) cur[u] = fuse_pack(key[u][e], id[u][e]);
                 best = cur[u] > best ? cur[u] : best;
             }
@@ -583,7 +587,8 @@ __global__ __launch_bounds__(ST_THREADS, RAG_STREAM_MINB) void flat_stream_kerne
     RAG_STAMP(4);
     if (*last == 0) return;
     __syncthreads();  // *last is read by everyone before the merge reuses the LDS
-    stream_fused_merge<METRIC>(smem_raw, cand_key, cand_id, (int)gridDim.x, nq, k, D, I, id_base);
+    if (k <= 10) stream_fused_merge<METRIC, 10>(smem_raw, cand_key, cand_id, (int)gridDim.x, nq, k, D, I, id_base);
+    else stream_fused_merge<METRIC, FUSE_MAX_K>(smem_raw, cand_key, cand_id, (int)gridDim.x, nq, k, D, I, id_base);
     RAG_STAMP(5);
 }
 
