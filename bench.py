@@ -436,22 +436,6 @@ def main():
     stages = main_run.stages() if (world > 1 or force_exchange) else None
     piped = main_run.pipelined(args.steps) if (world == 1 and args.out == "pinned" and not force_exchange) else None
 
-    # The metric has two halves (batch 1 and batch 1024).  `value` is the batch-1 half; the other
-    # is measured right after it on the same resident corpus (not part of `value`).
-    batch_leg = None
-    if nq == 1 and not args.no_batch_leg:
-        log("batch-1024 leg")
-        rb = Runner(env, n, d, k, 1024, args.storage, args.seed, args.out, index=main_run.index)
-        batch_leg = rb.leg("batch1024", 5, 1, "the headline corpus, nq=1024")
-        del rb
-
-    # Opt-in bfloat16 prefilter (rag_flat_prefilter; never part of `value`): the same corpus and queries with a
-    # bfloat16 copy of the rows as candidate source; results are those of the fp32 rows (compared below).
-    pf_leg = None
-    if world == 1 and nq == 1 and not bf and not args.no_batch_leg and not args.prefilter and k <= 16:
-        log("prefilter leg")
-        pf_leg = prefilter_leg(env, main_run, elapsed / args.steps * 1e3, args)
-
     out = None
     if rank == 0:
         Dn, In = main_run.check_plausible()     # outside the timed region: a plausible top-k
@@ -494,12 +478,15 @@ def main():
                              "note": "ms per step on each rank's stream; allgather_ms includes waiting for the slowest rank"}
         if piped is not None:
             out["pipelined"] = piped
-        if batch_leg is not None:
-            out["batch1024"] = batch_leg
-        if pf_leg is not None:
-            out["prefilter"] = pf_leg
 
-    # ---- N > 1: BASELINE config 4 (north_star's scaling workload), rows split over the ranks
+    # ---- N > 1: the batch half on the sharded corpus, then BASELINE config 4 (north_star's scaling workload), rows
+    # split over the ranks
+    batch_leg = None
+    if world > 1 and nq == 1 and not args.no_batch_leg:
+        log("batch-1024 leg")
+        rb = Runner(env, n, d, k, 1024, args.storage, args.seed, args.out, index=main_run.index)
+        batch_leg = rb.leg("batch1024", 5, 1, "the headline corpus, nq=1024")
+        del rb
     if world > 1 and not args.no_legs:
         del main_run
         torch.cuda.empty_cache()
@@ -517,28 +504,50 @@ def main():
         elif out is not None:
             out["c4"] = {"skipped": "%.0f GB per rank does not fit" % per_gb}
 
-    # ---- N = 1: the other BASELINE configs, time-bounded, beside the headline
-    if world == 1 and not args.no_legs and nq == 1 and not bf:
-        legs = [x for x in args.legs.split(",") if x]
+    # ---- N = 1: the other BASELINE configs, time-bounded, beside the headline.  Order matters on this part: for
+    # about a second after a bf16-MFMA leg (prefilter nq = 1024, c3) it gives a short HBM-bound kernel ~5 % less
+    # (1M x 384, nq = 1: 0.245 against 0.233 ms per launch, benchmarks/ab/run_r03_leg_order.sh), so the HBM-bound legs
+    # run first and the matrix-heavy ones last; every leg is its own measurement on its own resident index.
+    legs = [x for x in args.legs.split(",") if x] if (world == 1 and not args.no_legs and nq == 1 and not bf) else []
+    if "c2" in legs:
+        log("c2 leg: 1M x 384 fp32")
+        r = Runner(env, 1_000_000, 384, 10, 1, "f32", args.seed, args.out)
+        out["c2"] = {"nq1": r.leg("c2", 300, 20, "1M x 384 fp32, IndexFlatIP top-10, nq=1")}
+        del r
+    if "c4_shard" in legs:
+        log("c4_shard leg: one rank's 12.5M x 768 fp32 shard of config 4 at 8 GPUs")
+        r = Runner(env, 12_500_000, 768, 10, 1, "f32", args.seed, args.out)
+        out["c4_shard"] = r.leg("c4_shard", 30, 5, "12.5M x 768 fp32 = one of 8 shards of 100M x 768, top-10, nq=1")
+        del r
+    if "c2" in legs:
+        r = Runner(env, 1_000_000, 384, 10, 64, "f32", args.seed, args.out)
+        out["c2"]["nq64"] = r.leg("c2", 100, 10, "1M x 384 fp32, IndexFlatIP top-10, nq=64")
+        del r
+    # The metric has two halves (batch 1 and batch 1024).  `value` is the batch-1 half; the other
+    # is measured right after it on the same resident corpus (not part of `value`).
+    if world == 1 and nq == 1 and not args.no_batch_leg:
+        log("batch-1024 leg")
+        rb = Runner(env, n, d, k, 1024, args.storage, args.seed, args.out, index=main_run.index)
+        batch_leg = rb.leg("batch1024", 5, 1, "the headline corpus, nq=1024")
+        del rb
+
+    # Opt-in bfloat16 prefilter (rag_flat_prefilter; never part of `value`): the same corpus and queries with a
+    # bfloat16 copy of the rows as candidate source; results are those of the fp32 rows (compared below).
+    pf_leg = None
+    if world == 1 and nq == 1 and not bf and not args.no_batch_leg and not args.prefilter and k <= 16:
+        log("prefilter leg")
+        pf_leg = prefilter_leg(env, main_run, elapsed / args.steps * 1e3, args)
+    if rank == 0 and batch_leg is not None:
+        out["batch1024"] = batch_leg
+    if rank == 0 and pf_leg is not None:
+        out["prefilter"] = pf_leg
+    if legs:
         del main_run
         torch.cuda.empty_cache()
-        if "c2" in legs:
-            log("c2 leg: 1M x 384 fp32")
-            r = Runner(env, 1_000_000, 384, 10, 1, "f32", args.seed, args.out)
-            out["c2"] = {"nq1": r.leg("c2", 300, 20, "1M x 384 fp32, IndexFlatIP top-10, nq=1")}
-            del r
-            r = Runner(env, 1_000_000, 384, 10, 64, "f32", args.seed, args.out)
-            out["c2"]["nq64"] = r.leg("c2", 100, 10, "1M x 384 fp32, IndexFlatIP top-10, nq=64")
-            del r
         if "c3" in legs:
             log("c3 leg: 10M x 768 bf16, nq=1024, k=100")
             r = Runner(env, 10_000_000, 768, 100, 1024, "bf16", args.seed, args.out)
             out["c3"] = r.leg("c3", 8, 2, "10M x 768 bf16 rows, IndexFlatIP top-100, nq=1024")
-            del r
-        if "c4_shard" in legs:
-            log("c4_shard leg: one rank's 12.5M x 768 fp32 shard of config 4 at 8 GPUs")
-            r = Runner(env, 12_500_000, 768, 10, 1, "f32", args.seed, args.out)
-            out["c4_shard"] = r.leg("c4_shard", 30, 5, "12.5M x 768 fp32 = one of 8 shards of 100M x 768, top-10, nq=1")
             del r
         torch.cuda.empty_cache()
         if "c5" in legs:
