@@ -4,7 +4,9 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build
-for e in ${EXPS:-0 1 2 4 8 3 5 6}; do
+# (ablations with bit 4 -- no MFMA -- are NOT built by default: with the 16x16x32 path of r03 the run of
+# pipe_timing_4 ended in "an illegal memory access" and cost a GPU box; cause not found, do not run it on shared hardware)
+for e in ${EXPS:-0 1 2 8 3}; do
   ( f=""; [ $e -ne 0 ] && f="-DRAG_PIPE_EXP=$e"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $f -Iinclude -o benchmarks/pipe_timing_$e benchmarks/pipe_timing.hip rag_system_amd/csrc/lib.hip 2> build/pipe_timing_$e.log || { tail -20 build/pipe_timing_$e.log; exit 1; } ) &
 done

@@ -1,7 +1,7 @@
 // pipe_timing.hip -- the software-pipelined bf16 tile kernel (flat_mfma_pipe.h) alone, with the
 // ablation switches RAG_PIPE_EXP (1: no tile loads after the first row tile, 2: no fragment
-// reads, 4: no MFMA, 8: no barrier in the K loop; results are then meaningless, only the time is
-// read).  Not part of librag_mi355x.so.
+// reads, 4: no MFMA -- faulted the GPU with the 16x16x32 tiles of r03, do not run --, 8: no barrier in
+// the K loop; results are then meaningless, only the time is read).  Not part of librag_mi355x.so.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DRAG_PIPE_EXP=n] -Iinclude -o benchmarks/pipe_timing[_n] \
 //       benchmarks/pipe_timing.hip rag_system_amd/csrc/lib.hip
 //   ./benchmarks/pipe_timing [nq=1024] [d=768] [n=10000000] [stages=4] [zeros=0]
