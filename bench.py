@@ -20,7 +20,8 @@ carries `stages` (per-rank scan / all-gather / merge milliseconds) and a `c4` le
 config 4, 100M x 768 fp32 split over the ranks (north_star's scaling workload).
 
 N = 1 appends time-bounded legs for the other BASELINE configs beside the headline `value`
-(`batch1024`, `c2`, `c3`, `c4_shard`, `c5`), each with its own roofline; `--no-legs` skips them.
+(`c2`, `c4_shard`, `batch1024`, `prefilter`, `c3`, `c5` -- the HBM-bound ones first, the matrix-heavy ones last:
+DESIGN.md section 6), each with its own roofline; `--no-legs` skips them.
 
 The JSON line carries `roofline` (scan kernel, measured live with HIP events on the stream
 the kernel runs on) and `cpu_baseline` (oracle/flat_ref.c:flat_search_cpu_baseline, a
